@@ -1,0 +1,172 @@
+/*
+ * sparsify_hip.h -- C ABI of libsparsify_hip.so: the MI355X (gfx950) hot path of the
+ * sparse-autoencoder / transcoder train step.
+ *
+ * The reference (EleutherAI/sparsify v1.3.0) has no C ABI: its seams are Python
+ * (torch.autograd.Function / module-level function pointers). Each
+ * entry point below names the reference interface it replaces (file:line under the
+ * reference tree). The Python host side (sparsify_amd/) binds these with ctypes and
+ * keeps the reference's operator surface; INTEGRATION.md shows the binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host";
+ *  - tensors are dense row-major; N tokens, D = d_in, M latents, k active latents;
+ *  - indices cross the boundary as int64 (the reference's torch.topk dtype);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call
+ *    only enqueues work on that stream and never synchronises or allocates;
+ *  - dtype codes: SPHIP_F32 / SPHIP_BF16;
+ *  - return value 0 = success; otherwise an SPHIP_E* code, and sphip_last_error()
+ *    returns a thread-local, human readable message. Shapes are validated on the host
+ *    before any kernel is launched.
+ */
+#ifndef SPARSIFY_HIP_H
+#define SPARSIFY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHIP_ABI_VERSION 1
+
+enum { SPHIP_F32 = 0, SPHIP_BF16 = 1 };
+enum { SPHIP_OK = 0, SPHIP_EINVAL = 1, SPHIP_EUNSUPPORTED = 2, SPHIP_ELAUNCH = 3, SPHIP_EWORKSPACE = 4 };
+
+int sphip_abi_version(void);
+const char* sphip_last_error(void);
+
+/* ---------------------------------------------------------------- encoder (forward) */
+
+/* SparseCoder.encode prologue, sparse_coder.py:191-192: xc = x - b_dec (fp32 promote).
+ * Writes any of: xc_f32 (N,D) fp32, xc_bf16 (N,D) bf16 (the operand autocast would feed to
+ * the linear, sparse_coder.py:205-209). b_dec may be NULL (transcoder: plain cast). */
+int sphip_center_cast(const void* x, int x_dtype, const float* b_dec, float* xc_f32,
+                      void* xc_bf16, int64_t N, int64_t D, void* stream);
+
+/* fp32 -> bf16 (round to nearest even): the cast autocast applies to encoder.weight /
+ * encoder.bias on every call (sparse_coder.py:205-209); here done once per optimizer step. */
+int sphip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* FusedEncoder.forward, fused_encoder.py:29: pre = relu(x W^T + b).
+ * x (N,D), W (M,D), bias (M) or NULL, pre (N,M); all of `dtype` (bf16: MFMA bf16 with fp32
+ * accumulate, one rounding to bf16 in the epilogue; f32: exact-fp32 MFMA). relu = 0 keeps
+ * the raw affine output. Requires D % 8 == 0 (bf16) / D % 4 == 0 (f32). */
+int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, int dtype,
+                          int64_t N, int64_t D, int64_t M, int relu, void* stream);
+
+/* torch.topk(pre, k, dim=-1, sorted=False), fused_encoder.py:33 -- and, with keep_mask,
+ * torch.where(dead_mask[None], pre, -inf).topk(k_aux), sparse_coder.py:240-243.
+ * pre (N,M) of `dtype`; keep_mask (M) uint8 or NULL; vals (N,k) of `dtype`; idx (N,k) int64.
+ * Output order: value descending, ties by ascending index (deterministic).
+ * Masked-out latents rank as -inf and are selected only if fewer than k are kept. */
+int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, int64_t N, int64_t M,
+               int64_t k, void* vals, int64_t* idx, void* stream);
+
+/* groupmax, fused_encoder.py:34-43: max over k contiguous groups of M/k latents. M % k == 0. */
+int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, void* vals,
+                   int64_t* idx, void* stream);
+
+/* ---------------------------------------------------------------- sparse decode / gathers */
+
+/* decoder_impl / eager_decode / embedding_bag_k, utils.py:81-90, xformers.py:9-53, and the
+ * grad-input gather of FusedEncoder.backward, fused_encoder.py:58-64:
+ *   out[n,:] = sum_s coeff[n,s] * table[idx[n,s],:]  (+ bias[:] if bias != NULL)
+ * idx (N,k) int64 in [0,M); coeff (N,k) of coeff_dtype; table (M,D) fp32; out (N,D) fp32.
+ * fp32 accumulation in slot order s = 0..k-1 (deterministic). */
+int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff, int coeff_dtype,
+                               const float* table, const float* bias, float* out, int64_t N,
+                               int64_t k, int64_t M, int64_t D, void* stream);
+
+/* count_per_embedding_k + cumsum + map_embeddings_and_outputs_k, xformers.py:56-85,139-163:
+ * counting sort of the N*k (token,slot) entries by latent id.
+ *   seg_begin (M+1) int32: entries of latent j are perm[seg_begin[j] : seg_begin[j+1]]
+ *   perm (N*k) uint32   : entry ids e = n*k + s, ascending inside a segment (the reference's
+ *                         order inside a segment is arrival order of atomics; ours is fixed).
+ * Requires N*k < 2^31 (as xformers.py:156). workspace: sphip_segments_workspace_bytes. */
+size_t sphip_segments_workspace_bytes(int64_t N, int64_t k, int64_t M);
+int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_t M,
+                                uint32_t* perm, int32_t* seg_begin, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* aggregate_gradient_for_embedding_k, xformers.py:88-136 (decoder) and the index_add_
+ * weight/bias gradients of FusedEncoder.backward, fused_encoder.py:67-84 (encoder):
+ *   gW[j,:]      = sum_{e in seg j} coeff[e] * rows[e / k, :]          (all M rows written)
+ *   gbias[j]     = sum_{e in seg j} coeff[e]                           (if gbias != NULL)
+ *   dcoeff[e]    = < rows[e / k, :], W[j,:] >                          (if dcoeff != NULL)
+ * coeff (N,k) of coeff_dtype, rows (N,D) of rows_dtype, W (M,D) fp32, outputs fp32.
+ * Sums run in segment order, so results are bitwise reproducible. */
+int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                int coeff_dtype, const void* rows, int rows_dtype, const float* W,
+                                float* gW, float* gbias, float* dcoeff, int64_t N, int64_t k,
+                                int64_t M, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------- loss (FVU / AuxK) */
+
+/* sparse_coder.py:228: tv = sum((y - mean_0(y))^2). y (N,D) of y_dtype; out tv[0] fp32.
+ * workspace: sphip_reduce_workspace_bytes(N, D). Two-pass, fp32, fixed summation order. */
+size_t sphip_reduce_workspace_bytes(int64_t N, int64_t D);
+int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64_t D, float* tv,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* sparse_coder.py:225,253 (and :248, :260 with other operands): e = a - b; sq[0] = sum(e^2).
+ * a (N,D) of a_dtype, b (N,D) fp32, e (N,D) fp32 or NULL. */
+int sphip_residual_sumsq(const void* a, int a_dtype, const float* b, float* e, float* sq,
+                         int64_t N, int64_t D, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* out = (alpha * num[0] / den[0]) * in  -- e.g. dL/d sae_out = (-2 * go / tv) * e, the
+ * backward of sparse_coder.py:253-254. num/den are device scalars (no host sync). */
+int sphip_scale_by_ratio(const float* in, float* out, int64_t n, float alpha, const float* num,
+                         const float* den, void* stream);
+
+/* column sums: out[d] = sum_n a[n,d] (b_dec.grad from `+ self.b_dec`, sparse_coder.py:202;
+ * mean_0 for the step-0 bias init, trainer.py:399-404, with scale = 1/N). */
+int sphip_colsum(const void* a, int a_dtype, int64_t N, int64_t D, float scale, float* out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[d] = sum_j v[j] * W[j,d]: the column sum of FusedEncoder's grad-input,
+ * sum_n grad_x[n,:] = gb^T W_enc, which is all b_dec needs from it (sparse_coder.py:192 +
+ * fused_encoder.py:58-64). W (M,D) fp32, v (M) fp32, out (D) fp32. */
+int sphip_vec_mat(const float* v, const float* W, int64_t M, int64_t D, float scale, float* out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- dense parameter updates */
+
+/* set_decoder_norm_to_unit_norm, sparse_coder.py:273-279: W /= ||W||_row + eps, in place. */
+int sphip_unit_norm_rows(float* W, int64_t M, int64_t D, void* stream);
+
+/* remove_gradient_parallel_to_decoder_directions, sparse_coder.py:281-295, G in place. */
+int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, int64_t D, void* stream);
+
+/* SignSGD.step, sign_sgd.py:23: p -= lr * sign(g). Optionally refreshes a bf16 shadow of p
+ * in the same pass (bf16_shadow may be NULL). */
+int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow,
+                       void* stream);
+
+/* trainer.py:513-518 fused for one decoder matrix: projected gradient (not written back)
+ * followed by the SignSGD step on W, one pass over (W, G). */
+int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr,
+                                  void* stream);
+
+/* ---------------------------------------------------------------- dead-latent bookkeeping */
+
+/* trainer.py:422: did_fire[idx.flatten()] = True.  did_fire (M) uint8. */
+int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire,
+                     void* stream);
+
+/* trainer.py:531-538: counts += n_tokens; counts[did_fire] = 0; did_fire = 0. counts int64. */
+int sphip_dead_counter_step(int64_t* counts, uint8_t* did_fire, int64_t M, int64_t n_tokens,
+                            void* stream);
+
+/* trainer.py:415: dead_mask = counts > threshold; also returns the number of dead latents
+ * in n_dead[0] (int32, device) so the host syncs once (sparse_coder.py:231). */
+int sphip_dead_mask(const int64_t* counts, int64_t M, int64_t threshold, uint8_t* mask,
+                    int32_t* n_dead, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSIFY_HIP_H */

@@ -136,17 +136,27 @@ def forward_backward(
     loss_scale: float = 1.0,
     bf16: bool = False,
     need_grads: bool = True,
+    forced: dict | None = None,
 ):
     """SparseCoder.forward (sparse_coder.py:210-271) followed by the Trainer's
     ``(fvu + alpha*auxk + multi_topk/8).div(acc_steps).backward()`` (trainer.py:444-447).
 
     ``loss_scale`` is 1/acc_steps. Returns (out, grads): ``out`` mirrors ForwardOutput
     plus ``pre_acts``; ``grads`` maps parameter name -> dense fp32 gradient.
+
+    ``forced`` (tests only) replaces a selection by one made elsewhere: keys "top", "aux",
+    "multi" -> (acts, idx). bf16 pre-activations tie exactly at the k-th boundary on a
+    sizeable fraction of rows and torch.topk's pick among ties is unspecified, so the GPU
+    path is checked (a) for choosing an equally valid set and (b) against this oracle
+    evaluated on the very set it chose.
     """
+    forced = forced or {}
     W_enc, b_enc, W_dec, b_dec = P["W_enc"], P["b_enc"], P["W_dec"], P["b_dec"]
     W_skip = P.get("W_skip")
     M, D = W_enc.shape
     acts, idx, pre, xin = encode(x, P, cfg, bf16)
+    if "top" in forced:
+        acts, idx = forced["top"]
     if y is None:
         y = x
 
@@ -163,6 +173,8 @@ def forward_backward(
     aux = auxk_select(pre, dead_mask, y.shape[-1]) if dead_mask is not None else None
     if aux is not None:
         a_scale, a_acts, a_idx = aux
+        if "aux" in forced:
+            a_acts, a_idx = forced["aux"]
         e_hat = decode(a_idx, a_acts, W_dec, b_dec)
         auxk_loss = a_scale * (e_hat - e).pow(2).sum() / tv
     else:
@@ -172,7 +184,7 @@ def forward_backward(
 
     out_acts, out_idx, out_sae = acts, idx, sae_out
     if cfg.multi_topk:
-        m_acts, m_idx = pre.topk(4 * cfg.k, sorted=False)
+        m_acts, m_idx = forced["multi"] if "multi" in forced else pre.topk(4 * cfg.k, sorted=False)
         m_out = decode(m_idx, m_acts, W_dec, b_dec)
         multi_topk_fvu = (m_out - y).pow(2).sum() / tv
         out_acts, out_idx, out_sae = m_acts, m_idx, m_out

@@ -1,0 +1,90 @@
+"""Configuration dataclasses with the reference's field names and defaults
+(reference: sparsify/config.py:8-131). Plain dataclasses: the CLI parsing library the
+reference uses (simple_parsing) is out of scope; to_dict/from_dict keep the cfg.json
+format of sparse_coder.py:143-179 readable and writable."""
+from __future__ import annotations
+
+import dataclasses
+import json
+from dataclasses import dataclass, field
+from functools import partial
+from typing import Literal
+
+
+class _Serializable:
+    def to_dict(self) -> dict:
+        return dataclasses.asdict(self)
+
+    @classmethod
+    def from_dict(cls, d: dict, drop_extra_fields: bool = False):
+        names = {f.name for f in dataclasses.fields(cls)}
+        extra = set(d) - names
+        if extra and not drop_extra_fields:
+            raise ValueError(f"unknown fields for {cls.__name__}: {sorted(extra)}")
+        kw = {k: v for k, v in d.items() if k in names}
+        for f in dataclasses.fields(cls):
+            if f.name in kw and dataclasses.is_dataclass(f.type if isinstance(f.type, type) else None):
+                kw[f.name] = f.type.from_dict(kw[f.name], drop_extra_fields)
+        return cls(**kw)
+
+    def save_json(self, path: str) -> None:
+        with open(path, "w") as f:
+            json.dump(self.to_dict(), f)
+
+
+@dataclass
+class SparseCoderConfig(_Serializable):
+    activation: Literal["groupmax", "topk"] = "topk"
+    expansion_factor: int = 32
+    normalize_decoder: bool = True
+    num_latents: int = 0
+    k: int = 32
+    multi_topk: bool = False
+    skip_connection: bool = False
+    transcode: bool = False
+
+
+SaeConfig = SparseCoderConfig
+TranscoderConfig = partial(SparseCoderConfig, transcode=True)
+
+
+@dataclass
+class TrainConfig(_Serializable):
+    sae: SparseCoderConfig = field(default_factory=SparseCoderConfig)
+    batch_size: int = 32
+    grad_acc_steps: int = 1
+    micro_acc_steps: int = 1
+    loss_fn: Literal["ce", "fvu", "kl"] = "fvu"
+    optimizer: Literal["adam", "muon", "signum", "signsgd"] = "signum"
+    lr: float | None = None
+    lr_warmup_steps: int = 1000
+    k_decay_steps: int = 0
+    auxk_alpha: float = 0.0
+    dead_feature_threshold: int = 10_000_000
+    exclude_tokens: list[int] = field(default_factory=list)
+    hookpoints: list[str] = field(default_factory=list)
+    init_seeds: list[int] = field(default_factory=lambda: [0])
+    layers: list[int] = field(default_factory=list)
+    layer_stride: int = 1
+    distribute_modules: bool = False
+    save_every: int = 1000
+    save_best: bool = False
+    finetune: str | None = None
+    log_to_wandb: bool = False
+    run_name: str | None = None
+    wandb_log_frequency: int = 1
+    save_dir: str = "checkpoints"
+
+    def __post_init__(self):
+        """Same validation as config.py:119-131."""
+        if isinstance(self.sae, dict):
+            self.sae = SparseCoderConfig.from_dict(self.sae, drop_extra_fields=True)
+        if self.layers and self.layer_stride != 1:
+            raise ValueError("Cannot specify both `layers` and `layer_stride`.")
+        if self.distribute_modules and self.loss_fn in ("ce", "kl"):
+            raise ValueError(
+                "Distributing modules across ranks is not compatible with the "
+                "cross-entropy or KL divergence losses."
+            )
+        if not self.init_seeds:
+            raise ValueError("Must specify at least one random seed.")

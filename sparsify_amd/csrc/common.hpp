@@ -1,0 +1,93 @@
+// Shared host/device helpers for libsparsify_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sparsify_hip.h"
+
+namespace sphip {
+
+// ---------------------------------------------------------------- errors (host)
+void set_error(const char* fmt, ...);
+
+#define SPHIP_REQUIRE(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::sphip::set_error(__VA_ARGS__);      \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define SPHIP_CHECK_LAUNCH(name)                                                        \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            ::sphip::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return SPHIP_ELAUNCH;                                                       \
+        }                                                                               \
+    } while (0)
+
+static inline bool valid_dtype(int dt) { return dt == SPHIP_F32 || dt == SPHIP_BF16; }
+static inline size_t dtype_size(int dt) { return dt == SPHIP_BF16 ? 2 : 4; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+typedef unsigned short bf16_t;   // raw bf16 storage
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain cast -> v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float load(const float* p, int64_t i) { return p[i]; }
+    static __device__ __forceinline__ void store(float* p, int64_t i, float v) { p[i] = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+    static __device__ __forceinline__ void store(bf16_t* p, int64_t i, float v) { p[i] = f32_to_bf16(v); }
+};
+
+// load 4 consecutive elements as fp32 (pointer must be 4-element aligned)
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    float4 r;
+    r.x = __uint_as_float(u.x << 16);
+    r.y = __uint_as_float(u.x & 0xffff0000u);
+    r.z = __uint_as_float(u.y << 16);
+    r.w = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` = 16 floats of LDS.
+// Result valid in every thread. Fixed order => deterministic.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+}  // namespace sphip

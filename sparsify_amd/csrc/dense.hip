@@ -1,0 +1,293 @@
+// Dense, HBM-bound parameter-side kernels: encoder-input centring / casts, decoder row
+// normalisation, projected gradient, SignSGD, and the dead-latent counters.
+// Reference: sparsify/sparse_coder.py:191-192 (x - b_dec), :205-209 (autocast casts),
+// :273-279 (set_decoder_norm_to_unit_norm), :281-295
+// (remove_gradient_parallel_to_decoder_directions); sparsify/sign_sgd.py:15-23;
+// sparsify/trainer.py:415, :422, :531-538 (num_tokens_since_fired bookkeeping).
+//
+// gfx950 design: one 256-thread workgroup per decoder row for the row-wise ops (the 16 KB
+// row is read once from HBM; the second sweep hits L1/L2), flat grid-stride float4 kernels
+// for the element-wise ones. The fused decoder update reads (W, G) once and writes W once
+// instead of the reference's einsum / sub / sign / add passes.
+#include "common.hpp"
+
+namespace sphip {
+
+template <typename T>
+__global__ __launch_bounds__(256) void center_cast_kernel(const T* __restrict__ x, const float* __restrict__ b,
+                                                          float* __restrict__ of, bf16_t* __restrict__ ob,
+                                                          int64_t n, int D) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float v = Elem<T>::load(x, i);
+        if (b != nullptr) v -= b[i % D];
+        if (of != nullptr) of[i] = v;
+        if (ob != nullptr) ob[i] = f32_to_bf16(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void center_cast4_kernel(const T* __restrict__ x, const float* __restrict__ b,
+                                                           float* __restrict__ of, bf16_t* __restrict__ ob,
+                                                           int64_t n4, int D4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = load4(x + i * 4);
+        if (b != nullptr) {
+            const float4 bb = *reinterpret_cast<const float4*>(b + (i % D4) * 4);
+            v.x -= bb.x; v.y -= bb.y; v.z -= bb.z; v.w -= bb.w;
+        }
+        if (of != nullptr) *reinterpret_cast<float4*>(of + i * 4) = v;
+        if (ob != nullptr) {
+            const unsigned lo = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+            const unsigned hi = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>(ob + i * 4) = make_uint2(lo, hi);
+        }
+    }
+}
+
+// W[j,:] /= ||W[j,:]|| + eps
+template <int VEC>
+__global__ __launch_bounds__(256) void unit_norm_kernel(float* __restrict__ W, int D, float eps) {
+    __shared__ float red[16];
+    float* row = W + (int64_t)blockIdx.x * D;
+    float acc = 0.f;
+    for (int c = threadIdx.x * VEC; c < D; c += 256 * VEC) {
+        if (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + c);
+            acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+        } else {
+            const float v = row[c];
+            acc = fmaf(v, v, acc);
+        }
+    }
+    const float denom = sqrtf(block_sum(acc, red)) + eps;
+    for (int c = threadIdx.x * VEC; c < D; c += 256 * VEC) {
+        if (VEC == 4) {
+            float4 v = *reinterpret_cast<const float4*>(row + c);
+            v.x /= denom; v.y /= denom; v.z /= denom; v.w /= denom;
+            *reinterpret_cast<float4*>(row + c) = v;
+        } else {
+            row[c] = row[c] / denom;
+        }
+    }
+}
+
+// MODE 0: G -= <G,W> W (in place on G).   MODE 1: W -= lr * sign(G - <G,W> W) (G untouched).
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void decoder_row_kernel(float* __restrict__ W, float* __restrict__ G, int D,
+                                                          float lr) {
+    __shared__ float red[16];
+    float* w = W + (int64_t)blockIdx.x * D;
+    float* g = G + (int64_t)blockIdx.x * D;
+    float acc = 0.f;
+    for (int c = threadIdx.x * VEC; c < D; c += 256 * VEC) {
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(g + c);
+            const float4 b = *reinterpret_cast<const float4*>(w + c);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        } else {
+            acc = fmaf(g[c], w[c], acc);
+        }
+    }
+    const float par = block_sum(acc, red);
+    for (int c = threadIdx.x * VEC; c < D; c += 256 * VEC) {
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(g + c);
+            float4 b = *reinterpret_cast<const float4*>(w + c);
+            float4 p = make_float4(a.x - par * b.x, a.y - par * b.y, a.z - par * b.z, a.w - par * b.w);
+            if (MODE == 0) {
+                *reinterpret_cast<float4*>(g + c) = p;
+            } else {
+                b.x -= lr * (float)((p.x > 0.f) - (p.x < 0.f));
+                b.y -= lr * (float)((p.y > 0.f) - (p.y < 0.f));
+                b.z -= lr * (float)((p.z > 0.f) - (p.z < 0.f));
+                b.w -= lr * (float)((p.w > 0.f) - (p.w < 0.f));
+                *reinterpret_cast<float4*>(w + c) = b;
+            }
+        } else {
+            const float p = g[c] - par * w[c];
+            if (MODE == 0) g[c] = p;
+            else w[c] = w[c] - lr * (float)((p > 0.f) - (p < 0.f));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void signsgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                      float lr, bf16_t* __restrict__ shadow) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = *reinterpret_cast<const float4*>(p + i * 4);
+        const float4 a = *reinterpret_cast<const float4*>(g + i * 4);
+        v.x -= lr * (float)((a.x > 0.f) - (a.x < 0.f));
+        v.y -= lr * (float)((a.y > 0.f) - (a.y < 0.f));
+        v.z -= lr * (float)((a.z > 0.f) - (a.z < 0.f));
+        v.w -= lr * (float)((a.w > 0.f) - (a.w < 0.f));
+        *reinterpret_cast<float4*>(p + i * 4) = v;
+        if (shadow != nullptr) {
+            const unsigned lo = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+            const unsigned hi = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>(shadow + i * 4) = make_uint2(lo, hi);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float a = g[i];
+        const float v = p[i] - lr * (float)((a > 0.f) - (a < 0.f));
+        p[i] = v;
+        if (shadow != nullptr) shadow[i] = f32_to_bf16(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_fired_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t M,
+                                                         uint8_t* __restrict__ fired) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t j = idx[i];
+        if (j >= 0 && j < M) fired[j] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void dead_counter_kernel(int64_t* __restrict__ counts, uint8_t* __restrict__ fired,
+                                                           int64_t M, int64_t n_tokens) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < M) {
+        counts[j] = fired[j] ? 0 : counts[j] + n_tokens;
+        fired[j] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void dead_mask_kernel(const int64_t* __restrict__ counts, int64_t M,
+                                                        int64_t threshold, uint8_t* __restrict__ mask,
+                                                        int* __restrict__ n_dead) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int dead = (j < M && counts[j] > threshold) ? 1 : 0;
+    if (j < M) mask[j] = (uint8_t)dead;
+    const int c = wave_sum_i(dead);
+    if ((threadIdx.x & 63) == 0 && c != 0) atomicAdd(n_dead, c);
+}
+
+static inline unsigned flat_grid(int64_t work_items) {
+    int64_t b = cdiv(work_items, 256);
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (unsigned)b;
+}
+
+}  // namespace sphip
+
+extern "C" int sphip_center_cast(const void* x, int x_dtype, const float* b_dec, float* xc_f32, void* xc_bf16,
+                                 int64_t N, int64_t D, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(x_dtype), SPHIP_EINVAL, "center_cast: bad dtype");
+    SPHIP_REQUIRE(x && (xc_f32 || xc_bf16), SPHIP_EINVAL, "center_cast: null pointer");
+    SPHIP_REQUIRE(N > 0 && D > 0 && D < (1ll << 31), SPHIP_EINVAL, "center_cast: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = N * D;
+    const bool vec = (D % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)xc_f32 & 15) == 0) &&
+                     (((uintptr_t)xc_bf16 & 7) == 0) && (((uintptr_t)b_dec & 15) == 0);
+    if (vec) {
+        if (x_dtype == SPHIP_F32) hipLaunchKernelGGL((center_cast4_kernel<float>), dim3(flat_grid(n / 4)), dim3(256), 0, s, (const float*)x, b_dec, xc_f32, (bf16_t*)xc_bf16, n / 4, (int)(D / 4));
+        else hipLaunchKernelGGL((center_cast4_kernel<bf16_t>), dim3(flat_grid(n / 4)), dim3(256), 0, s, (const bf16_t*)x, b_dec, xc_f32, (bf16_t*)xc_bf16, n / 4, (int)(D / 4));
+    } else {
+        if (x_dtype == SPHIP_F32) hipLaunchKernelGGL((center_cast_kernel<float>), dim3(flat_grid(n)), dim3(256), 0, s, (const float*)x, b_dec, xc_f32, (bf16_t*)xc_bf16, n, (int)D);
+        else hipLaunchKernelGGL((center_cast_kernel<bf16_t>), dim3(flat_grid(n)), dim3(256), 0, s, (const bf16_t*)x, b_dec, xc_f32, (bf16_t*)xc_bf16, n, (int)D);
+    }
+    SPHIP_CHECK_LAUNCH("center_cast");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(src && dst, SPHIP_EINVAL, "cast_f32_to_bf16: null pointer");
+    SPHIP_REQUIRE(n > 0, SPHIP_EINVAL, "cast_f32_to_bf16: empty");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (n % 4 == 0) && (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 7) == 0);
+    if (vec) hipLaunchKernelGGL((center_cast4_kernel<float>), dim3(flat_grid(n / 4)), dim3(256), 0, s, src, (const float*)nullptr, (float*)nullptr, (bf16_t*)dst, n / 4, 1);
+    else hipLaunchKernelGGL((center_cast_kernel<float>), dim3(flat_grid(n)), dim3(256), 0, s, src, (const float*)nullptr, (float*)nullptr, (bf16_t*)dst, n, 1);
+    SPHIP_CHECK_LAUNCH("cast_f32_to_bf16");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_unit_norm_rows(float* W, int64_t M, int64_t D, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W, SPHIP_EINVAL, "unit_norm_rows: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "unit_norm_rows: bad shape");
+    const float eps = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
+    hipStream_t s = (hipStream_t)stream;
+    if (D % 4 == 0 && ((uintptr_t)W & 15) == 0) hipLaunchKernelGGL((unit_norm_kernel<4>), dim3((unsigned)M), dim3(256), 0, s, W, (int)D, eps);
+    else hipLaunchKernelGGL((unit_norm_kernel<1>), dim3((unsigned)M), dim3(256), 0, s, W, (int)D, eps);
+    SPHIP_CHECK_LAUNCH("unit_norm_rows");
+    return SPHIP_OK;
+}
+
+static int decoder_row_op(float* W, float* G, int64_t M, int64_t D, float lr, int mode, void* stream, const char* name) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && G, SPHIP_EINVAL, "%s: null pointer", name);
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "%s: bad shape", name);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = D % 4 == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)G & 15) == 0;
+    dim3 grid((unsigned)M), block(256);
+    if (mode == 0) {
+        if (vec) hipLaunchKernelGGL((decoder_row_kernel<4, 0>), grid, block, 0, s, W, G, (int)D, lr);
+        else hipLaunchKernelGGL((decoder_row_kernel<1, 0>), grid, block, 0, s, W, G, (int)D, lr);
+    } else {
+        if (vec) hipLaunchKernelGGL((decoder_row_kernel<4, 1>), grid, block, 0, s, W, G, (int)D, lr);
+        else hipLaunchKernelGGL((decoder_row_kernel<1, 1>), grid, block, 0, s, W, G, (int)D, lr);
+    }
+    SPHIP_CHECK_LAUNCH(name);
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, int64_t D, void* stream) {
+    return decoder_row_op(const_cast<float*>(W), G, M, D, 0.f, 0, stream, "remove_parallel_grad");
+}
+
+extern "C" int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr, void* stream) {
+    return decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
+}
+
+extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(p && g, SPHIP_EINVAL, "signsgd_step: null pointer");
+    SPHIP_REQUIRE(n > 0, SPHIP_EINVAL, "signsgd_step: empty");
+    SPHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)bf16_shadow & 7) == 0, SPHIP_EINVAL,
+                  "signsgd_step: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(signsgd_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, n, lr, (bf16_t*)bf16_shadow);
+    SPHIP_CHECK_LAUNCH("signsgd_step");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(idx && did_fire, SPHIP_EINVAL, "mark_fired: null pointer");
+    SPHIP_REQUIRE(n_entries > 0 && M > 0, SPHIP_EINVAL, "mark_fired: bad shape");
+    hipLaunchKernelGGL(mark_fired_kernel, dim3(flat_grid(n_entries)), dim3(256), 0, (hipStream_t)stream, idx, n_entries, M, did_fire);
+    SPHIP_CHECK_LAUNCH("mark_fired");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_dead_counter_step(int64_t* counts, uint8_t* did_fire, int64_t M, int64_t n_tokens, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(counts && did_fire, SPHIP_EINVAL, "dead_counter_step: null pointer");
+    SPHIP_REQUIRE(M > 0 && n_tokens >= 0, SPHIP_EINVAL, "dead_counter_step: bad shape");
+    hipLaunchKernelGGL(dead_counter_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, counts, did_fire, M, n_tokens);
+    SPHIP_CHECK_LAUNCH("dead_counter_step");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_dead_mask(const int64_t* counts, int64_t M, int64_t threshold, uint8_t* mask, int32_t* n_dead,
+                               void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(counts && mask && n_dead, SPHIP_EINVAL, "dead_mask: null pointer");
+    SPHIP_REQUIRE(M > 0, SPHIP_EINVAL, "dead_mask: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(n_dead, 0, sizeof(int32_t), s) != hipSuccess) {
+        set_error("dead_mask: memset failed");
+        return SPHIP_ELAUNCH;
+    }
+    hipLaunchKernelGGL(dead_mask_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, counts, M, threshold, mask, n_dead);
+    SPHIP_CHECK_LAUNCH("dead_mask");
+    return SPHIP_OK;
+}

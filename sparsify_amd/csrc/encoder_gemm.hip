@@ -1,0 +1,224 @@
+// Encoder pre-activations: pre[n, m] = relu( sum_d x[n,d] * W[m,d] + b[m] )
+// Reference: FusedEncoder.forward, sparsify/fused_encoder.py:29 (F.relu(F.linear(x, W, b)));
+// under the reference's bf16 autocast (sparse_coder.py:205-209) all three operands are bf16
+// and the result is bf16 -- that is the SPHIP_BF16 instantiation. The SPHIP_F32 one is the
+// path a direct fp32 call of fused_encoder takes (tests/test_encode.py).
+//
+// gfx950 design (v1): 128(latent) x 128(token) output tile per 256-thread workgroup, four
+// waves as 2x2, each wave 2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16 /
+// v_mfma_f32_32x32x2_f32). Both operands are K-contiguous ("TN"), so an LDS tile row is
+// 128 B of K (64 bf16 / 32 f32) and every lane's MFMA fragment is one 16-B ds_read_b128.
+// The 16-B chunks of a row are XOR-swizzled with (row>>1)&7 so the 16 lanes of a
+// ds_read_b128 lane group hit 16 different bank slots. W is the MFMA "A" operand (latents
+// on the accumulator rows): each lane then owns 4 consecutive latents of one token per
+// register quad, i.e. contiguous 8-B (bf16) / 16-B (f32) output stores.
+// LDS is double buffered (64 KB, 2 workgroups per CU); the next K tile is fetched into
+// registers while the current one is multiplied.
+// Workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a contiguous range
+// of 8-latent-tile x 8-token-tile patches.
+#include "common.hpp"
+
+namespace sphip {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = 128;        // rows of W / rows of X per workgroup
+constexpr int ROW_BYTES = 128;   // K bytes per LDS row
+constexpr int CHUNKS = 8;        // 16-B chunks per LDS row
+
+template <typename T> struct GemmT;
+template <> struct GemmT<bf16_t> { static constexpr int EPC = 8; };   // elements per 16-B chunk
+template <> struct GemmT<float> { static constexpr int EPC = 4; };
+
+__device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& c, bf16_t) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& c, float) {
+    // lane half h holds k = 4h + i of this 8-wide k group for MFMA i; A and B agree, so
+    // the four MFMAs together sum all 8 k values.
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store4(float* p, const float (&v)[4], bool vec) {
+    if (vec) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3]; }
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4], bool vec) {
+    const bf16_t b0 = f32_to_bf16(v[0]), b1 = f32_to_bf16(v[1]), b2 = f32_to_bf16(v[2]), b3 = f32_to_bf16(v[3]);
+    if (vec) *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)b0 | ((unsigned)b1 << 16), (unsigned)b2 | ((unsigned)b3 << 16));
+    else { p[0] = b0; p[1] = b1; p[2] = b2; p[3] = b3; }
+}
+
+// blockIdx -> (latent tile, token tile): XCD-contiguous ranges, then 8-tall bands swept
+// token-tile by token-tile (any tile counts).
+__device__ __forceinline__ void tile_coords(int tilesM, int tilesN, int& tm, int& tn) {
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned xcd = bid & 7, slot = bid >> 3;
+    const unsigned q = nb >> 3, r = nb & 7;
+    const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const unsigned band = 8u * (unsigned)tilesN;
+    const unsigned g = L / band, within = L % band;
+    const unsigned first = g * 8;
+    const unsigned gsize = min((unsigned)tilesM - first, 8u);
+    tm = (int)(first + within % gsize);
+    tn = (int)(within / gsize);
+}
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256, 2) void encoder_gemm_kernel(const T* __restrict__ X,
+                                                              const T* __restrict__ W,
+                                                              const T* __restrict__ bias,
+                                                              T* __restrict__ P, int N, int D, int M,
+                                                              int tilesM, int tilesN) {
+    constexpr int EPC = GemmT<T>::EPC;
+    constexpr int BKE = CHUNKS * EPC;   // K elements per tile
+    __shared__ uint4 lds[2][2][TILE * CHUNKS];   // [buffer][W|X][row*8 + swizzled chunk]
+
+    int tm, tn;
+    tile_coords(tilesM, tilesN, tm, tn);
+    const int m0 = tm * TILE, n0 = tn * TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging coordinates: chunk c = tid + 256*i  ->  row = (tid>>3) + 32*i, ch = tid&7
+    const int ch = tid & 7, srow = tid >> 3;
+    const int kTiles = (D + BKE - 1) / BKE;
+
+    uint4 ra[4], rb[4];
+    auto fetch = [&](int kt) {
+        const int kel = kt * BKE + ch * EPC;
+        const bool kin = kel < D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const int gm = m0 + row, gn = n0 + row;
+            ra[i] = (kin && gm < M) ? *reinterpret_cast<const uint4*>(W + (int64_t)gm * D + kel) : make_uint4(0, 0, 0, 0);
+            rb[i] = (kin && gn < N) ? *reinterpret_cast<const uint4*>(X + (int64_t)gn * D + kel) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const int phys = ch ^ ((row >> 1) & 7);
+            lds[buf][0][row * CHUNKS + phys] = ra[i];
+            lds[buf][1][row * CHUNKS + phys] = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < kTiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < kTiles) fetch(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = wm * 64 + mi * 32 + r;
+                a[mi] = lds[buf][0][row * CHUNKS + ((2 * ks + h) ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int row = wn * 64 + ni * 32 + r;
+                b[ni] = lds[buf][1][row * CHUNKS + ((2 * ks + h) ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) mma_chunk(a[mi], b[ni], acc[mi][ni], T{});
+        }
+        if (kt + 1 < kTiles) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: + bias, relu, one rounding to T, 4 consecutive latents per store
+    const bool vec = (M & 3) == 0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + wm * 64 + mi * 32 + 8 * q + 4 * h;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m + j < M) bv[j] = Elem<T>::load(bias, m + j);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int n = n0 + wn * 64 + ni * 32 + r;
+                if (n >= N || m >= M) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[mi][ni][4 * q + j] + bv[j];
+                    v[j] = RELU ? (t > 0.f ? t : 0.f) : t;
+                }
+                T* dst = P + (int64_t)n * M + m;
+                if (m + 3 < M) store4(dst, v, vec);
+                else
+                    for (int j = 0; j < 4 && m + j < M; ++j) Elem<T>::store(dst, j, v[j]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_gemm(const void* x, const void* W, const void* bias, void* pre, int64_t N, int64_t D,
+                       int64_t M, int relu, hipStream_t s) {
+    const int tilesM = (int)cdiv(M, TILE), tilesN = (int)cdiv(N, TILE);
+    const int64_t nblocks = (int64_t)tilesM * tilesN;
+    SPHIP_REQUIRE(nblocks < (1ll << 31), SPHIP_EUNSUPPORTED, "encoder_preacts: grid too large");
+    dim3 grid((unsigned)nblocks), block(256);
+    if (relu)
+        hipLaunchKernelGGL((encoder_gemm_kernel<T, true>), grid, block, 0, s, (const T*)x, (const T*)W,
+                           (const T*)bias, (T*)pre, (int)N, (int)D, (int)M, tilesM, tilesN);
+    else
+        hipLaunchKernelGGL((encoder_gemm_kernel<T, false>), grid, block, 0, s, (const T*)x, (const T*)W,
+                           (const T*)bias, (T*)pre, (int)N, (int)D, (int)M, tilesM, tilesN);
+    SPHIP_CHECK_LAUNCH("encoder_preacts");
+    return SPHIP_OK;
+}
+
+}  // namespace sphip
+
+extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, int dtype,
+                                     int64_t N, int64_t D, int64_t M, int relu, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "encoder_preacts: bad dtype %d", dtype);
+    SPHIP_REQUIRE(x && W && pre, SPHIP_EINVAL, "encoder_preacts: null pointer");
+    SPHIP_REQUIRE(N > 0 && D > 0 && M > 0, SPHIP_EINVAL, "encoder_preacts: empty shape N=%lld D=%lld M=%lld",
+                  (long long)N, (long long)D, (long long)M);
+    SPHIP_REQUIRE(N < (1ll << 31) && M < (1ll << 31) && D < (1ll << 31), SPHIP_EUNSUPPORTED,
+                  "encoder_preacts: dimension exceeds int32");
+    const int epc = dtype == SPHIP_BF16 ? 8 : 4;
+    SPHIP_REQUIRE(D % epc == 0, SPHIP_EUNSUPPORTED, "encoder_preacts: D=%lld must be a multiple of %d",
+                  (long long)D, epc);
+    SPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)pre & 15) == 0,
+                  SPHIP_EINVAL, "encoder_preacts: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SPHIP_BF16) return launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
+    return launch_gemm<float>(x, W, bias, pre, N, D, M, relu, s);
+}

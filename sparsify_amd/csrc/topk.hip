@@ -1,0 +1,346 @@
+// Row-wise top-k / group-max selection over the pre-activations.
+// Reference: torch.topk(preacts, k, dim=-1, sorted=False), sparsify/fused_encoder.py:33;
+// the AuxK variant torch.where(dead_mask[None], pre_acts, -inf).topk(k_aux),
+// sparsify/sparse_coder.py:240-243; groupmax, fused_encoder.py:34-43.
+//
+// gfx950 design: one 1024-thread workgroup (16 waves) per token row; keys are the
+// order-preserving unsigned image of the value bits (16 bit for bf16, 32 bit for f32).
+//   fast path  (k <= 1024): sweep 1 takes each thread's maximum key; the k-th largest of
+//              the 1024 thread maxima (bisection on the key bits, one barrier per bit) is a
+//              proven lower bound tau of the k-th largest element. Sweep 2 (row now in
+//              L2 / Infinity Cache) appends every element >= tau to an LDS candidate list
+//              (wave-aggregated LDS atomic), typically ~1.1 k entries. A bitonic sort of the
+//              candidates on (key desc, index asc) yields the exact, deterministic top-k.
+//   exact path (k > 1024, or more than CAP candidates, e.g. rows full of ties): bisection
+//              of the k-th largest key over the whole row, then an index-ordered emission
+//              (block scans) that takes ties in ascending index order.
+// Both paths choose the same SET: all keys above the k-th key plus the lowest-index ties.
+#include "common.hpp"
+
+namespace sphip {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_WAVES = TK_THREADS / 64;
+constexpr int TK_CAP = 4096;   // candidate capacity (8 B each -> 32 KB LDS)
+
+__device__ __forceinline__ unsigned to_key(bf16_t u) {
+    const unsigned v = u;
+    return (v & 0x8000u) ? ((~v) & 0xffffu) : (v | 0x8000u);
+}
+__device__ __forceinline__ unsigned to_key(float f) {
+    const unsigned v = __float_as_uint(f);
+    return (v & 0x80000000u) ? ~v : (v | 0x80000000u);
+}
+template <typename T> struct KeyOf;
+template <> struct KeyOf<bf16_t> {
+    static constexpr int BITS = 16;
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ bf16_t value(unsigned key) {
+        if (key == 0) return (bf16_t)0xff80u;   // masked-out latent -> -inf
+        return (bf16_t)((key & 0x8000u) ? (key & 0x7fffu) : ((~key) & 0xffffu));
+    }
+};
+template <> struct KeyOf<float> {
+    static constexpr int BITS = 32;
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ float value(unsigned key) {
+        if (key == 0) return __uint_as_float(0xff800000u);
+        return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+    }
+};
+
+// Loads VEC consecutive keys starting at element i (i % VEC == 0 when ALIGNED).
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ void load_keys(const T* row, const uint8_t* keep, int i, int M,
+                                          unsigned (&key)[KeyOf<T>::VEC]) {
+    constexpr int V = KeyOf<T>::VEC;
+    if (ALIGNED) {
+        uint4 raw = *reinterpret_cast<const uint4*>(row + i);
+        const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int j = 0; j < V; ++j) key[j] = to_key(e[j]);
+        if (keep != nullptr) {
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                if (!keep[i + j]) key[j] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = i + j;
+            key[j] = (c < M && (keep == nullptr || keep[c])) ? to_key(row[c]) : 0u;
+        }
+    }
+}
+
+// block-wide sum of a per-thread count; `slot` alternates between calls so one barrier
+// per call is enough. part = [2][TK_WAVES] in LDS.
+__device__ __forceinline__ unsigned block_count(unsigned c, unsigned* part, int slot) {
+    c = (unsigned)wave_sum_i((int)c);
+    unsigned* p = part + slot * TK_WAVES;
+    if ((threadIdx.x & 63) == 0) p[threadIdx.x >> 6] = c;
+    __syncthreads();
+    unsigned t = 0;
+#pragma unroll
+    for (int w = 0; w < TK_WAVES; ++w) t += p[w];
+    return t;
+}
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ pre,
+                                                          const uint8_t* __restrict__ keep, int M,
+                                                          int k, T* __restrict__ vals,
+                                                          int64_t* __restrict__ idx_out) {
+    constexpr int V = KeyOf<T>::VEC;
+    constexpr int BITS = KeyOf<T>::BITS;
+    __shared__ unsigned long long cand[TK_CAP];
+    __shared__ unsigned part[2 * TK_WAVES];
+    __shared__ unsigned s_count;
+    __shared__ unsigned scan_tot[TK_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* row = pre + (int64_t)blockIdx.x * M;
+    T* out_v = vals + (int64_t)blockIdx.x * k;
+    int64_t* out_i = idx_out + (int64_t)blockIdx.x * k;
+    const int span = TK_THREADS * V;
+    int slot = 0;
+
+    bool exact = k > TK_THREADS;
+    if (!exact) {
+        // ---- sweep 1: thread maxima
+        unsigned tmax = 0;
+        for (int i = tid * V; i < M; i += span) {
+            unsigned key[V];
+            load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+            for (int j = 0; j < V; ++j) tmax = max(tmax, key[j]);
+        }
+        // ---- k-th largest thread maximum (lower bound of the k-th largest element)
+        unsigned tau = 0;
+        for (int bit = BITS - 1; bit >= 0; --bit) {
+            const unsigned t = tau | (1u << bit);
+            const unsigned c = block_count(tmax >= t ? 1u : 0u, part, slot);
+            slot ^= 1;
+            if (c >= (unsigned)k) tau = t;
+        }
+        // ---- sweep 2: collect candidates >= tau
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < M; i0 += span) {
+            const int i = i0 + tid * V;
+            unsigned key[V];
+            unsigned vmax = 0;
+            if (i < M) {
+                load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+                for (int j = 0; j < V; ++j) vmax = max(vmax, (ALIGNED || i + j < M) ? key[j] : 0u);
+            }
+            const bool any = (i < M) && (vmax >= tau);
+            if (__ballot(any) == 0ull) continue;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const bool hit = any && (i + j < M) && key[j] >= tau;
+                const unsigned long long m = __ballot(hit);
+                if (m == 0ull) continue;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (hit) {
+                    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < (unsigned)TK_CAP)
+                        cand[pos] = ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(i + j));
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned count = s_count;
+        if (count > (unsigned)TK_CAP) {
+            exact = true;   // block-uniform
+        } else {
+            // ---- bitonic sort, descending on (key, ~index)
+            unsigned P = 2;
+            while (P < count) P <<= 1;
+            for (unsigned i = count + tid; i < P; i += TK_THREADS) cand[i] = 0ull;
+            for (unsigned size = 2; size <= P; size <<= 1) {
+                for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                    __syncthreads();
+                    for (unsigned t = tid; t < (P >> 1); t += TK_THREADS) {
+                        const unsigned lo = 2 * t - (t & (stride - 1));
+                        const unsigned hi = lo + stride;
+                        const bool desc = (lo & size) == 0;
+                        const unsigned long long a = cand[lo], b = cand[hi];
+                        if ((a < b) == desc) { cand[lo] = b; cand[hi] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < k; t += TK_THREADS) {
+                const unsigned long long e = cand[t];
+                out_v[t] = KeyOf<T>::value((unsigned)(e >> 32));
+                out_i[t] = (int64_t)(~(unsigned)e);
+            }
+            return;
+        }
+    }
+
+    // ---- exact path: bisection of the k-th largest key over the whole row
+    unsigned kth = 0;
+    for (int bit = BITS - 1; bit >= 0; --bit) {
+        const unsigned t = kth | (1u << bit);
+        unsigned c = 0;
+        for (int i = tid * V; i < M; i += span) {
+            unsigned key[V];
+            load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+            for (int j = 0; j < V; ++j) c += ((ALIGNED || i + j < M) && key[j] >= t) ? 1u : 0u;
+        }
+        const unsigned tot = block_count(c, part, slot);
+        slot ^= 1;
+        if (tot >= (unsigned)k) kth = t;
+    }
+    unsigned cgt = 0;
+    for (int i = tid * V; i < M; i += span) {
+        unsigned key[V];
+        load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+        for (int j = 0; j < V; ++j) cgt += ((ALIGNED || i + j < M) && key[j] > kth) ? 1u : 0u;
+    }
+    const unsigned count_gt = block_count(cgt, part, slot);
+    slot ^= 1;
+    const unsigned need_eq = (unsigned)k - count_gt;
+
+    // index-ordered emission: [0, count_gt) strictly greater, [count_gt, k) lowest-index ties
+    unsigned run_gt = 0, run_eq = 0;
+    for (int i0 = 0; i0 < M; i0 += span) {
+        const int i = i0 + tid * V;
+        unsigned key[V];
+        unsigned g = 0, q = 0;
+        if (i < M) {
+            load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const bool in = ALIGNED || i + j < M;
+                g += (in && key[j] > kth) ? 1u : 0u;
+                q += (in && key[j] == kth) ? 1u : 0u;
+            }
+        }
+        // block exclusive scan of (g | q << 16); per-thread counts <= 8, totals <= 8192
+        unsigned packed = g | (q << 16);
+        unsigned incl = packed;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        __syncthreads();   // scan_tot free for reuse
+        if (lane == 63) scan_tot[wave] = incl;
+        __syncthreads();
+        unsigned wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < TK_WAVES; ++w) {
+            const unsigned t = scan_tot[w];
+            if (w < wave) wave_off += t;
+            total += t;
+        }
+        const unsigned excl = wave_off + incl - packed;
+        unsigned pg = run_gt + (excl & 0xffffu);
+        unsigned pq = run_eq + (excl >> 16);
+        if (i < M) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (!(ALIGNED || i + j < M)) continue;
+                if (key[j] > kth) {
+                    out_v[pg] = KeyOf<T>::value(key[j]);
+                    out_i[pg] = i + j;
+                    ++pg;
+                } else if (key[j] == kth) {
+                    if (pq < need_eq) {
+                        out_v[count_gt + pq] = KeyOf<T>::value(key[j]);
+                        out_i[count_gt + pq] = i + j;
+                    }
+                    ++pq;
+                }
+            }
+        }
+        run_gt += total & 0xffffu;
+        run_eq += total >> 16;
+    }
+}
+
+// groupmax: one wave per (token, group); first maximal index wins (torch.max semantics).
+template <typename T>
+__global__ __launch_bounds__(256) void groupmax_kernel(const T* __restrict__ pre, int M, int k, int width,
+                                                       int64_t total, T* __restrict__ vals,
+                                                       int64_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= total) return;
+    const int64_t n = gid / k;
+    const int g = (int)(gid % k);
+    const T* p = pre + n * M + (int64_t)g * width;
+    unsigned long long best = 0ull;
+    for (int i = lane; i < width; i += 64) {
+        const unsigned long long e = ((unsigned long long)to_key(p[i]) << 32) | (unsigned)(~(unsigned)i);
+        best = e > best ? e : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if (lane == 0) {
+        vals[gid] = KeyOf<T>::value((unsigned)(best >> 32));
+        idx_out[gid] = (int64_t)g * width + (int64_t)(~(unsigned)best);
+    }
+}
+
+}  // namespace sphip
+
+extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, int64_t N, int64_t M, int64_t k,
+                          void* vals, int64_t* idx, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "topk: bad dtype %d", dtype);
+    SPHIP_REQUIRE(pre && vals && idx, SPHIP_EINVAL, "topk: null pointer");
+    SPHIP_REQUIRE(N > 0 && M > 0, SPHIP_EINVAL, "topk: empty shape N=%lld M=%lld", (long long)N, (long long)M);
+    SPHIP_REQUIRE(k > 0 && k <= M, SPHIP_EINVAL, "topk: k=%lld out of range for M=%lld (selected index out of range)",
+                  (long long)k, (long long)M);
+    SPHIP_REQUIRE(M < (1ll << 31) - 65536 && N < (1ll << 31), SPHIP_EUNSUPPORTED, "topk: shape exceeds int32");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)N), block(TK_THREADS);
+    const int vec = dtype == SPHIP_BF16 ? 8 : 4;
+    const bool aligned = (M % vec == 0) && (((uintptr_t)pre & 15) == 0);
+    if (dtype == SPHIP_BF16) {
+        if (aligned)
+            hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (int)M, (int)k, (bf16_t*)vals, idx);
+        else
+            hipLaunchKernelGGL((topk_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (int)M, (int)k, (bf16_t*)vals, idx);
+    } else {
+        if (aligned)
+            hipLaunchKernelGGL((topk_kernel<float, true>), grid, block, 0, s, (const float*)pre, keep_mask, (int)M, (int)k, (float*)vals, idx);
+        else
+            hipLaunchKernelGGL((topk_kernel<float, false>), grid, block, 0, s, (const float*)pre, keep_mask, (int)M, (int)k, (float*)vals, idx);
+    }
+    SPHIP_CHECK_LAUNCH("topk");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx,
+                              void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "groupmax: bad dtype %d", dtype);
+    SPHIP_REQUIRE(pre && vals && idx, SPHIP_EINVAL, "groupmax: null pointer");
+    SPHIP_REQUIRE(N > 0 && M > 0 && k > 0 && k <= M, SPHIP_EINVAL, "groupmax: bad shape N=%lld M=%lld k=%lld",
+                  (long long)N, (long long)M, (long long)k);
+    SPHIP_REQUIRE(M % k == 0, SPHIP_EINVAL, "groupmax: M=%lld is not divisible by k=%lld", (long long)M, (long long)k);
+    SPHIP_REQUIRE(M < (1ll << 31), SPHIP_EUNSUPPORTED, "groupmax: M exceeds int32");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = N * k;
+    SPHIP_REQUIRE(cdiv(total, 4) < (1ll << 31), SPHIP_EUNSUPPORTED, "groupmax: grid too large");
+    dim3 grid((unsigned)cdiv(total, 4)), block(256);
+    if (dtype == SPHIP_BF16)
+        hipLaunchKernelGGL((groupmax_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)pre, (int)M, (int)k, (int)(M / k), total, (bf16_t*)vals, idx);
+    else
+        hipLaunchKernelGGL((groupmax_kernel<float>), grid, block, 0, s, (const float*)pre, (int)M, (int)k, (int)(M / k), total, (float*)vals, idx);
+    SPHIP_CHECK_LAUNCH("groupmax");
+    return SPHIP_OK;
+}

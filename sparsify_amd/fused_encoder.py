@@ -1,0 +1,140 @@
+"""Fused encoder op with the reference's surface (sparsify/fused_encoder.py:7-103):
+``fused_encoder(input, weight, bias, k, activation) -> EncoderOutput`` and the
+``FusedEncoder`` autograd.Function, running on the HIP kernels of libsparsify_hip.
+
+Forward : pre = relu(x W^T + b) (bf16 MFMA under autocast, exact-fp32 MFMA otherwise),
+          then row top-k / groupmax.
+Backward: only the k selected columns -- segmented (latent-major) weight/bias gradient and,
+          if asked for, the gathered grad-input. ``grad_preacts`` is ignored exactly as in
+          the reference (fused_encoder.py:53,87).
+"""
+from __future__ import annotations
+
+from typing import Literal, NamedTuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+class EncoderOutput(NamedTuple):
+    top_acts: Tensor
+    """Activations of the top-k latents."""
+
+    top_indices: Tensor
+    """Indices of the top-k features."""
+
+    pre_acts: Tensor
+    """Activations before the top-k selection."""
+
+
+_shadows: dict[int, tuple] = {}
+
+
+def bf16_shadow(t: Tensor) -> Tensor:
+    """bf16 copy of an fp32 parameter, re-cast only when the parameter changed.
+
+    Autocast re-casts encoder.weight (2 GiB read at the headline shape) on every call
+    (sparse_coder.py:205-209 + fused_encoder.py:29); the values are identical, we just keep
+    them until the optimizer bumps the parameter's version."""
+    if t.dtype == torch.bfloat16:
+        return t
+    key = t.data_ptr()
+    hit = _shadows.get(key)
+    if hit is not None and hit[0] == (t._version, tuple(t.shape)):
+        return hit[1]
+    buf = hit[1] if hit is not None and hit[1].shape == t.shape else None
+    sh = ops.cast_bf16(t.detach().contiguous(), buf)
+    _shadows[key] = ((t._version, tuple(t.shape)), sh)
+    return sh
+
+
+def register_bf16_shadow(t: Tensor, shadow: Tensor) -> None:
+    """Tell the cache that `shadow` already equals bf16(t) (written by a fused update)."""
+    _shadows[t.data_ptr()] = ((t._version, tuple(t.shape)), shadow)
+
+
+def peek_bf16_shadow(t: Tensor) -> Tensor | None:
+    hit = _shadows.get(t.data_ptr())
+    return hit[1] if hit is not None and hit[1].shape == t.shape else None
+
+
+def _autocast_bf16() -> bool:
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+class FusedEncoder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, weight, bias, k: int, activation: Literal["groupmax", "topk"], b_dec=None):
+        """
+        input:  (N, D)      weight: (M, D)      bias: (M,)
+        k:      number of latents to keep per row
+        b_dec:  optional (D,) decoder bias to subtract from the input first
+                (SparseCoder.encode, sparse_coder.py:191-192), fused here.
+        """
+        if activation not in ("topk", "groupmax"):
+            raise ValueError(f"Unknown activation: {activation}")
+        lead = input.shape[:-1]
+        x2 = input.reshape(-1, input.shape[-1]).contiguous()
+        low = _autocast_bf16() or (weight.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16)
+
+        if b_dec is not None:
+            rows, x_low = ops.center_cast(x2, b_dec.detach().contiguous(), want_f32=True, want_bf16=low)
+        else:
+            rows = x2
+            x_low = None
+            if low:
+                x_low = x2 if x2.dtype == torch.bfloat16 else ops.center_cast(x2, None, False, True)[1]
+        if low:
+            pre = ops.encoder_preacts(x_low, bf16_shadow(weight), None if bias is None else bf16_shadow(bias))
+        else:
+            xf = rows if rows.dtype == torch.float32 else ops.center_cast(rows, None, True, False)[0]
+            pre = ops.encoder_preacts(xf, weight.detach().contiguous(),
+                                      None if bias is None else bias.detach().contiguous())
+
+        if activation == "topk":
+            values, indices = ops.topk(pre, k)
+        else:
+            values, indices = ops.groupmax(pre, k)
+        ops.forget_segments(indices)
+
+        ctx.save_for_backward(rows, weight, bias, indices, b_dec)
+        ctx.k = k
+        ctx.lead = lead
+        ctx.in_shape = input.shape
+        ctx.mark_non_differentiable(indices, pre)
+        return (values.reshape(*lead, k), indices.reshape(*lead, k), pre.reshape(*lead, pre.shape[-1]))
+
+    @staticmethod
+    def backward(ctx, grad_values, grad_indices, grad_preacts):
+        rows, weight, bias, indices, b_dec = ctx.saved_tensors
+        grad_input = grad_weight = grad_bias = grad_bdec = None
+        M = weight.shape[0]
+        gv = grad_values.reshape(-1, ctx.k).contiguous()
+        if weight.dtype != torch.float32:
+            raise TypeError("FusedEncoder.backward needs fp32 master weights (trainer.py:85-87)")
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_bdec = b_dec is not None and ctx.needs_input_grad[5]
+
+        if need_w or need_b or need_bdec:
+            seg = ops.cached_segments(indices, M)
+            grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True)
+            if bias is None:
+                gb_full, grad_bias = grad_bias, None
+            else:
+                gb_full = grad_bias
+        if need_x:
+            gx = ops.gather_rows_weighted(indices, gv, weight.detach())
+            grad_input = gx.reshape(ctx.in_shape)
+            if need_bdec:
+                grad_bdec = ops.colsum(gx, -1.0)
+        elif need_bdec:
+            # sum_n grad_x[n,:] = gb^T W : one pass over W instead of an (N,k)-row gather
+            grad_bdec = ops.vec_mat(gb_full, weight.detach(), -1.0)
+        return grad_input, grad_weight, grad_bias, None, None, grad_bdec
+
+
+def fused_encoder(input, weight, bias, k: int, activation: Literal["groupmax", "topk"]) -> EncoderOutput:
+    """nn.Linear + ReLU + `activation`, with the sparse backward (fused_encoder.py:90-103)."""
+    return EncoderOutput(*FusedEncoder.apply(input, weight, bias, k, activation))

@@ -1,0 +1,337 @@
+"""Thin tensor-level wrappers over the C ABI (include/sparsify_hip.h).
+
+PyTorch is used only as plumbing here: device memory (torch.empty), the current HIP
+stream and dtype bookkeeping. Every wrapper validates devices/dtypes/contiguity on the
+host and then passes raw pointers; nothing in this module computes with torch ops.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import BF16, F32, check
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}; the HIP path handles float32 and bfloat16")
+
+
+def _stream(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(t: Tensor, name: str, dtype=None, ndim: int | None = None) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: sparsify_amd runs on the MI355X HIP path only (no CPU fallback)"
+        )
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.ndim != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t: Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+_workspaces: dict[tuple, Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int, tag: str) -> Tensor:
+    """Grow-only per-(device, stream, tag) scratch buffer (uint8, 256-B aligned by the allocator)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ encoder forward
+def center_cast(x: Tensor, b_dec: Tensor | None, want_f32: bool, want_bf16: bool):
+    """(x - b_dec) as fp32 and/or bf16. reference: sparse_coder.py:191-192 (+ autocast cast)."""
+    _req(x, "x", ndim=2)
+    N, D = x.shape
+    if b_dec is not None:
+        _req(b_dec, "b_dec", torch.float32, 1)
+    of = torch.empty(N, D, dtype=torch.float32, device=x.device) if want_f32 else None
+    ob = torch.empty(N, D, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    check(_lib.load().sphip_center_cast(x.data_ptr(), _dt(x), _ptr(b_dec), _ptr(of), _ptr(ob), N, D, _stream(x)),
+          "sphip_center_cast")
+    return of, ob
+
+
+def cast_bf16(src: Tensor, out: Tensor | None = None) -> Tensor:
+    _req(src, "src", torch.float32)
+    if out is None:
+        out = torch.empty_like(src, dtype=torch.bfloat16)
+    check(_lib.load().sphip_cast_f32_to_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream(src)),
+          "sphip_cast_f32_to_bf16")
+    return out
+
+
+def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True) -> Tensor:
+    """relu(x @ W.T + bias); reference: fused_encoder.py:29."""
+    _req(x, "x", ndim=2)
+    _req(W, "weight", x.dtype, 2)
+    if bias is not None:
+        _req(bias, "bias", x.dtype, 1)
+    N, D = x.shape
+    M = W.shape[0]
+    if W.shape[1] != D or (bias is not None and bias.shape[0] != M):
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(W.shape)}")
+    pre = torch.empty(N, M, dtype=x.dtype, device=x.device)
+    check(_lib.load().sphip_encoder_preacts(x.data_ptr(), W.data_ptr(), _ptr(bias), pre.data_ptr(), _dt(x), N, D, M,
+                                           int(relu), _stream(x)), "sphip_encoder_preacts")
+    return pre
+
+
+def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None):
+    """torch.topk(pre, k, sorted=False) (optionally restricted to keep_mask); fused_encoder.py:33."""
+    _req(pre, "pre_acts", ndim=2)
+    N, M = pre.shape
+    if keep_mask is not None:
+        _req(keep_mask, "keep_mask", ndim=1)
+        if keep_mask.dtype == torch.bool:
+            keep_mask = keep_mask.view(torch.uint8)
+        if keep_mask.dtype != torch.uint8 or keep_mask.shape[0] != M:
+            raise ValueError("keep_mask must be a (M,) bool/uint8 tensor")
+    vals = torch.empty(N, k, dtype=pre.dtype, device=pre.device)
+    idx = torch.empty(N, k, dtype=torch.int64, device=pre.device)
+    check(_lib.load().sphip_topk(pre.data_ptr(), _dt(pre), _ptr(keep_mask), N, M, k, vals.data_ptr(), idx.data_ptr(),
+                                _stream(pre)), "sphip_topk")
+    return vals, idx
+
+
+def groupmax(pre: Tensor, k: int):
+    _req(pre, "pre_acts", ndim=2)
+    N, M = pre.shape
+    vals = torch.empty(N, k, dtype=pre.dtype, device=pre.device)
+    idx = torch.empty(N, k, dtype=torch.int64, device=pre.device)
+    check(_lib.load().sphip_groupmax(pre.data_ptr(), _dt(pre), N, M, k, vals.data_ptr(), idx.data_ptr(), _stream(pre)),
+          "sphip_groupmax")
+    return vals, idx
+
+
+# ------------------------------------------------------------------ gathers / segments
+def gather_rows_weighted(idx: Tensor, coeff: Tensor, table: Tensor, bias: Tensor | None = None) -> Tensor:
+    """out[n] = sum_s coeff[n,s] * table[idx[n,s]] (+ bias); utils.py:81-85 / fused_encoder.py:58-64."""
+    _req(idx, "indices", torch.int64, 2)
+    _req(coeff, "coeff", ndim=2)
+    _req(table, "table", torch.float32, 2)
+    if bias is not None:
+        _req(bias, "bias", torch.float32, 1)
+    N, k = idx.shape
+    M, D = table.shape
+    if coeff.shape != idx.shape:
+        raise ValueError(f"coeff {tuple(coeff.shape)} vs indices {tuple(idx.shape)}")
+    out = torch.empty(N, D, dtype=torch.float32, device=table.device)
+    check(_lib.load().sphip_gather_rows_weighted(idx.data_ptr(), coeff.data_ptr(), _dt(coeff), table.data_ptr(),
+                                                _ptr(bias), out.data_ptr(), N, k, M, D, _stream(table)),
+          "sphip_gather_rows_weighted")
+    return out
+
+
+class LatentSegments:
+    """perm / seg_begin of one (N,k) index tensor over M latents (xformers.py:139-163)."""
+
+    __slots__ = ("perm", "seg_begin", "N", "k", "M")
+
+    def __init__(self, perm, seg_begin, N, k, M):
+        self.perm, self.seg_begin, self.N, self.k, self.M = perm, seg_begin, N, k, M
+
+
+def build_latent_segments(idx: Tensor, M: int) -> LatentSegments:
+    _req(idx, "indices", torch.int64, 2)
+    N, k = idx.shape
+    lib = _lib.load()
+    nbytes = lib.sphip_segments_workspace_bytes(N, k, M)
+    ws = _workspace(idx.device, nbytes, "segments")
+    perm = torch.empty(N * k, dtype=torch.int32, device=idx.device)       # holds uint32 entry ids
+    seg = torch.empty(M + 1, dtype=torch.int32, device=idx.device)
+    check(lib.sphip_build_latent_segments(idx.data_ptr(), N, k, M, perm.data_ptr(), seg.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _stream(idx)), "sphip_build_latent_segments")
+    return LatentSegments(perm, seg, N, k, M)
+
+
+_segment_cache: dict[int, tuple] = {}
+
+
+def forget_segments(idx: Tensor) -> None:
+    """Called by every forward that takes `idx`: drops a stale entry left by an earlier
+    tensor that lived at the same address."""
+    _segment_cache.pop(idx.data_ptr(), None)
+
+
+def cached_segments(idx: Tensor, M: int) -> LatentSegments:
+    """Decoder and encoder backward share one index tensor; sort it once per step.
+
+    Entries are created in backward only and dropped by the next forward that sees the same
+    address (forget_segments), and the tensor is kept alive by the autograd graph in
+    between, so a hit always belongs to this very tensor."""
+    key = idx.data_ptr()
+    hit = _segment_cache.get(key)
+    if hit is not None and hit[0] == (idx._version, tuple(idx.shape), M):
+        return hit[1]
+    seg = build_latent_segments(idx, M)
+    if len(_segment_cache) > 16:
+        _segment_cache.clear()
+    _segment_cache[key] = ((idx._version, tuple(idx.shape), M), seg)
+    return seg
+
+
+def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: Tensor | None = None,
+                          want_bias: bool = False, want_dcoeff: bool = False):
+    """(gW, gbias, dcoeff); xformers.py:88-136 and fused_encoder.py:67-84."""
+    _req(coeff, "coeff", ndim=2)
+    _req(rows, "rows", ndim=2)
+    N, k, M = seg.N, seg.k, seg.M
+    D = rows.shape[1]
+    if tuple(coeff.shape) != (N, k) or rows.shape[0] != N:
+        raise ValueError("segmented_weight_grad: shape mismatch")
+    if W is not None:
+        _req(W, "W", torch.float32, 2)
+        if tuple(W.shape) != (M, D):
+            raise ValueError("segmented_weight_grad: W shape mismatch")
+    if want_dcoeff and W is None:
+        raise ValueError("dcoeff needs W")
+    gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
+    gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
+    dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
+    check(_lib.load().sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
+                                                 _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
+                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), N, k, M, D, _stream(rows)),
+          "sphip_segmented_weight_grad")
+    return gW, gb, dc
+
+
+# ------------------------------------------------------------------ loss pieces
+def _red_ws(t: Tensor, N: int, D: int) -> Tensor:
+    return _workspace(t.device, _lib.load().sphip_reduce_workspace_bytes(N, D), "reduce")
+
+
+def total_variance(y: Tensor) -> Tensor:
+    _req(y, "y", ndim=2)
+    N, D = y.shape
+    tv = torch.empty(1, dtype=torch.float32, device=y.device)
+    ws = _red_ws(y, N, D)
+    check(_lib.load().sphip_total_variance(y.data_ptr(), _dt(y), N, D, tv.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream(y)), "sphip_total_variance")
+    return tv
+
+
+def residual_sumsq(a: Tensor, b: Tensor, want_residual: bool = True):
+    """e = a - b (fp32), sq = sum(e^2)."""
+    _req(a, "a", ndim=2)
+    _req(b, "b", torch.float32, 2)
+    if a.shape != b.shape:
+        raise ValueError("residual_sumsq: shape mismatch")
+    N, D = a.shape
+    e = torch.empty(N, D, dtype=torch.float32, device=a.device) if want_residual else None
+    sq = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = _red_ws(a, N, D)
+    check(_lib.load().sphip_residual_sumsq(a.data_ptr(), _dt(a), b.data_ptr(), _ptr(e), sq.data_ptr(), N, D,
+                                          ws.data_ptr(), ws.numel(), _stream(a)), "sphip_residual_sumsq")
+    return e, sq
+
+
+def scale_by_ratio(src: Tensor, alpha: float, num: Tensor | None, den: Tensor | None, out: Tensor | None = None):
+    _req(src, "in", torch.float32)
+    if out is None:
+        out = torch.empty_like(src)
+    check(_lib.load().sphip_scale_by_ratio(src.data_ptr(), out.data_ptr(), src.numel(), float(alpha), _ptr(num),
+                                          _ptr(den), _stream(src)), "sphip_scale_by_ratio")
+    return out
+
+
+def colsum(a: Tensor, scale: float = 1.0) -> Tensor:
+    _req(a, "a", ndim=2)
+    N, D = a.shape
+    out = torch.empty(D, dtype=torch.float32, device=a.device)
+    ws = _red_ws(a, N, D)
+    check(_lib.load().sphip_colsum(a.data_ptr(), _dt(a), N, D, float(scale), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream(a)), "sphip_colsum")
+    return out
+
+
+def vec_mat(v: Tensor, W: Tensor, scale: float = 1.0) -> Tensor:
+    _req(v, "v", torch.float32, 1)
+    _req(W, "W", torch.float32, 2)
+    M, D = W.shape
+    out = torch.empty(D, dtype=torch.float32, device=W.device)
+    ws = _red_ws(W, M, D)
+    check(_lib.load().sphip_vec_mat(v.data_ptr(), W.data_ptr(), M, D, float(scale), out.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), _stream(W)), "sphip_vec_mat")
+    return out
+
+
+# ------------------------------------------------------------------ dense updates
+def unit_norm_rows_(W: Tensor) -> Tensor:
+    _req(W, "W_dec", torch.float32, 2)
+    check(_lib.load().sphip_unit_norm_rows(W.data_ptr(), W.shape[0], W.shape[1], _stream(W)), "sphip_unit_norm_rows")
+    return W
+
+
+def remove_parallel_grad_(G: Tensor, W: Tensor) -> Tensor:
+    _req(G, "W_dec.grad", torch.float32, 2)
+    _req(W, "W_dec", torch.float32, 2)
+    check(_lib.load().sphip_remove_parallel_grad(G.data_ptr(), W.data_ptr(), W.shape[0], W.shape[1], _stream(W)),
+          "sphip_remove_parallel_grad")
+    return G
+
+
+def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = None) -> Tensor:
+    _req(p, "param", torch.float32)
+    _req(g, "grad", torch.float32)
+    if g.shape != p.shape:
+        raise ValueError("signsgd: grad shape mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    check(_lib.load().sphip_signsgd_step(p.data_ptr(), g.data_ptr(), p.numel(), float(lr), _ptr(bf16_shadow),
+                                        _stream(p)), "sphip_signsgd_step")
+    return p
+
+
+def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float) -> Tensor:
+    _req(W, "W_dec", torch.float32, 2)
+    _req(G, "W_dec.grad", torch.float32, 2)
+    check(_lib.load().sphip_decoder_project_signsgd(W.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1], float(lr),
+                                                   _stream(W)), "sphip_decoder_project_signsgd")
+    return W
+
+
+# ------------------------------------------------------------------ dead-latent bookkeeping
+def mark_fired_(did_fire: Tensor, idx: Tensor) -> Tensor:
+    _req(idx, "indices", torch.int64)
+    _req(did_fire, "did_fire", ndim=1)
+    buf = did_fire.view(torch.uint8) if did_fire.dtype == torch.bool else did_fire
+    check(_lib.load().sphip_mark_fired(idx.data_ptr(), idx.numel(), buf.shape[0], buf.data_ptr(), _stream(idx)),
+          "sphip_mark_fired")
+    return did_fire
+
+
+def dead_counter_step_(counts: Tensor, did_fire: Tensor, n_tokens: int) -> None:
+    _req(counts, "num_tokens_since_fired", torch.int64, 1)
+    buf = did_fire.view(torch.uint8) if did_fire.dtype == torch.bool else did_fire
+    check(_lib.load().sphip_dead_counter_step(counts.data_ptr(), buf.data_ptr(), counts.shape[0], int(n_tokens),
+                                             _stream(counts)), "sphip_dead_counter_step")
+
+
+def dead_mask(counts: Tensor, threshold: int):
+    """(mask bool (M,), n_dead int32 device scalar); trainer.py:415 + sparse_coder.py:231."""
+    _req(counts, "num_tokens_since_fired", torch.int64, 1)
+    M = counts.shape[0]
+    mask = torch.empty(M, dtype=torch.bool, device=counts.device)
+    n_dead = torch.empty(1, dtype=torch.int32, device=counts.device)
+    check(_lib.load().sphip_dead_mask(counts.data_ptr(), M, int(threshold), mask.view(torch.uint8).data_ptr(),
+                                     n_dead.data_ptr(), _stream(counts)), "sphip_dead_mask")
+    return mask, n_dead

@@ -1,0 +1,34 @@
+"""SignSGD with the reference's optimizer surface (sparsify/sign_sgd.py:5-23); the update
+p -= lr * sign(grad) is one HIP pass per parameter, which can also refresh the bf16 shadow
+the encoder GEMM reads (so the next step needs no separate cast)."""
+from __future__ import annotations
+
+import torch
+from torch.optim import Optimizer
+
+from . import ops
+from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
+
+
+class SignSGD(Optimizer):
+    """Steepest descent in the L-infty norm. From <https://arxiv.org/abs/1802.04434>"""
+
+    def __init__(self, params, lr: float = 1e-3):
+        if lr <= 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        super().__init__(params, {"lr": lr})
+
+    @torch.no_grad()
+    def step(self, closure: None = None) -> None:
+        assert closure is None, "Closure is not supported."
+        for group in self.param_groups:
+            lr = group["lr"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                shadow = peek_bf16_shadow(p)
+                ops.signsgd_step_(p.data, g, lr, shadow)
+                torch.autograd.graph.increment_version(p)
+                if shadow is not None:
+                    register_bf16_shadow(p, shadow)

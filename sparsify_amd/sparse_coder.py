@@ -1,0 +1,240 @@
+"""SparseCoder with the reference's surface (sparsify/sparse_coder.py:19-299): same
+parameters, same method names, same ForwardOutput -- executed by the HIP kernels of
+libsparsify_hip (encoder GEMM + top-k, sparse decode, fused FVU/AuxK reductions,
+segmented weight gradients)."""
+from __future__ import annotations
+
+import json
+from fnmatch import fnmatch
+from pathlib import Path
+from typing import NamedTuple
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .config import SparseCoderConfig
+from .fused_encoder import EncoderOutput, FusedEncoder
+from .utils import SparseDecode, decoder_impl
+
+
+class ForwardOutput(NamedTuple):
+    sae_out: Tensor
+
+    latent_acts: Tensor
+    """Activations of the top-k latents."""
+
+    latent_indices: Tensor
+    """Indices of the top-k features."""
+
+    fvu: Tensor
+    """Fraction of variance unexplained."""
+
+    auxk_loss: Tensor
+    """AuxK loss, if applicable."""
+
+    multi_topk_fvu: Tensor
+    """Multi-TopK FVU, if applicable."""
+
+
+class ResidualLoss(torch.autograd.Function):
+    """loss = sum((target - pred)^2) / tv, plus the residual itself (non-differentiable).
+
+    Fuses sparse_coder.py:225 + :253-254 (and :248-249, :260): one pass produces e and the
+    sum of squares; the backward is one scaled copy, dL/dpred = (-2 g / tv) e."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Tensor, tv: Tensor):
+        p2 = pred.reshape(-1, pred.shape[-1]).contiguous()
+        t2 = target.reshape(-1, target.shape[-1]).contiguous()
+        e, sq = ops.residual_sumsq(t2, p2, want_residual=True)
+        loss = ops.scale_by_ratio(sq, 1.0, None, tv)
+        ctx.save_for_backward(e, tv)
+        ctx.pred_shape = pred.shape
+        e_out = e.reshape(pred.shape)
+        ctx.mark_non_differentiable(e_out)
+        return loss.reshape(()), e_out
+
+    @staticmethod
+    def backward(ctx, g_loss, g_e):
+        e, tv = ctx.saved_tensors
+        g = g_loss.reshape(1).contiguous().float()
+        return ops.scale_by_ratio(e, -2.0, g, tv).reshape(ctx.pred_shape), None, None
+
+
+class SparseCoder(nn.Module):
+    def __init__(
+        self,
+        d_in: int,
+        cfg: SparseCoderConfig,
+        device: str | torch.device = "cpu",
+        dtype: torch.dtype | None = None,
+        *,
+        decoder: bool = True,
+    ):
+        super().__init__()
+        self.cfg = cfg
+        self.d_in = d_in
+        self.num_latents = cfg.num_latents or d_in * cfg.expansion_factor
+
+        self.encoder = nn.Linear(d_in, self.num_latents, device=device, dtype=dtype)
+        self.encoder.bias.data.zero_()
+
+        if decoder:
+            if cfg.transcode:
+                # transcoder: zeros (sparse_coder.py:58-59)
+                self.W_dec = nn.Parameter(torch.zeros_like(self.encoder.weight.data))
+            else:
+                # autoencoder: copy of the encoder, rows normalised (sparse_coder.py:62-65).
+                # Initialisation runs once and may happen on the host before .to(device),
+                # so it is written with plain tensor ops; the per-step normalisation below
+                # (set_decoder_norm_to_unit_norm) is the HIP kernel.
+                w = self.encoder.weight.data.clone()
+                if cfg.normalize_decoder:
+                    eps = torch.finfo(w.dtype).eps
+                    w /= torch.norm(w, dim=1, keepdim=True) + eps
+                self.W_dec = nn.Parameter(w)
+        else:
+            self.W_dec = None
+
+        self.b_dec = nn.Parameter(torch.zeros(d_in, dtype=dtype, device=device))
+        self.W_skip = (
+            nn.Parameter(torch.zeros(d_in, d_in, device=device, dtype=dtype))
+            if cfg.skip_connection
+            else None
+        )
+
+    # ------------------------------------------------------------------ (de)serialisation
+    # Checkpoint layout of the reference: {path}/cfg.json + {path}/sae.safetensors with keys
+    # W_dec, b_dec, encoder.weight, encoder.bias[, W_skip] (sparse_coder.py:134-179).
+    @staticmethod
+    def load_many(name: str, local: bool = True, layers: list[str] | None = None,
+                  device: str | torch.device = "cpu", *, decoder: bool = True,
+                  pattern: str | None = None) -> dict[str, "SparseCoder"]:
+        if not local:
+            raise NotImplementedError("hub downloads are out of scope (no network); pass local=True")
+        repo_path = Path(name)
+        pat = pattern + "/*" if pattern is not None else None
+        if layers is not None:
+            return {layer: SparseCoder.load_from_disk(repo_path / layer, device=device, decoder=decoder)
+                    for layer in sorted(layers, key=_natural_key)}
+        dirs = [f for f in repo_path.iterdir() if f.is_dir() and (pat is None or fnmatch(f.name, pat))]
+        return {f.name: SparseCoder.load_from_disk(f, device=device, decoder=decoder)
+                for f in sorted(dirs, key=lambda f: _natural_key(f.name))}
+
+    @staticmethod
+    def load_from_disk(path: Path | str, device: str | torch.device = "cpu", *, decoder: bool = True) -> "SparseCoder":
+        from safetensors import safe_open
+        from safetensors.torch import load_model
+
+        path = Path(path)
+        with open(path / "cfg.json", "r") as f:
+            cfg_dict = json.load(f)
+            d_in = cfg_dict.pop("d_in")
+            cfg = SparseCoderConfig.from_dict(cfg_dict, drop_extra_fields=True)
+        st_path = str(path / "sae.safetensors")
+        with safe_open(st_path, framework="pt", device="cpu") as f:
+            first_key = next(iter(f.keys()))
+            reference_dtype = f.get_tensor(first_key).dtype
+        sae = SparseCoder(d_in, cfg, device=device, decoder=decoder, dtype=reference_dtype)
+        load_model(model=sae, filename=st_path, device=str(device), strict=decoder)
+        return sae
+
+    def save_to_disk(self, path: Path | str):
+        from safetensors.torch import save_model
+
+        path = Path(path)
+        path.mkdir(parents=True, exist_ok=True)
+        save_model(self, str(path / "sae.safetensors"))
+        with open(path / "cfg.json", "w") as f:
+            json.dump({**self.cfg.to_dict(), "d_in": self.d_in}, f)
+
+    @property
+    def device(self):
+        return self.encoder.weight.device
+
+    @property
+    def dtype(self):
+        return self.encoder.weight.dtype
+
+    # ------------------------------------------------------------------ hot path
+    def encode(self, x: Tensor) -> EncoderOutput:
+        """Encode the input and select the top-k latents (sparse_coder.py:189-196).
+        The `x - b_dec` of the reference is fused into the encoder op."""
+        b_dec = None if self.cfg.transcode else self.b_dec
+        return EncoderOutput(*FusedEncoder.apply(
+            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.cfg.activation, b_dec))
+
+    def decode(self, top_acts: Tensor, top_indices: Tensor) -> Tensor:
+        """sparse_coder.py:198-202; the bias add is fused into the gather kernel."""
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        idx = top_indices.reshape(-1, top_indices.shape[-1]).contiguous()
+        acts = top_acts.to(self.dtype).reshape(-1, top_acts.shape[-1])
+        y = SparseDecode.apply(idx, self.W_dec, acts, self.b_dec)
+        return y.reshape(*top_indices.shape[:-1], self.d_in)
+
+    # Same autocast wrapper as the reference (sparse_coder.py:204-209): the encoder linear
+    # (and the skip matmul) run in bf16, everything else in fp32.
+    @torch.autocast("cuda", dtype=torch.bfloat16, enabled=torch.cuda.is_available())
+    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None) -> ForwardOutput:
+        top_acts, top_indices, pre_acts = self.encode(x)
+
+        if y is None:
+            y = x
+
+        sae_out = self.decode(top_acts, top_indices)
+        if self.W_skip is not None:
+            sae_out = sae_out + x.to(self.dtype) @ self.W_skip.mT
+
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        total_variance = ops.total_variance(y2)                     # sparse_coder.py:228
+        fvu, e = ResidualLoss.apply(sae_out, y, total_variance)      # :225, :253-254
+
+        if dead_mask is not None and (num_dead := int(dead_mask.sum())) > 0:
+            k_aux = y.shape[-1] // 2                                  # :233
+            scale = min(num_dead / k_aux, 1.0)
+            k_aux = min(k_aux, num_dead)
+            pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
+            auxk_acts, auxk_indices = ops.topk(pre2, k_aux, keep_mask=dead_mask)      # :240-243
+            # the gradient w.r.t. auxk_acts would flow into pre_acts, which the encoder
+            # backward drops (fused_encoder.py:53,87) -- so it is never computed here.
+            e_hat = self.decode(auxk_acts, auxk_indices).reshape(e.shape)
+            auxk_sq, _ = ResidualLoss.apply(e_hat, e, total_variance)                  # :248-249
+            auxk_loss = scale * auxk_sq
+        else:
+            auxk_loss = sae_out.new_tensor(0.0)
+
+        if self.cfg.multi_topk:
+            pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
+            top_acts, top_indices = ops.topk(pre2, 4 * self.cfg.k)                    # :257
+            top_acts = top_acts.reshape(*x.shape[:-1], -1)
+            top_indices = top_indices.reshape(*x.shape[:-1], -1)
+            sae_out = self.decode(top_acts, top_indices)
+            multi_topk_fvu, _ = ResidualLoss.apply(sae_out, y, total_variance)         # :260
+        else:
+            multi_topk_fvu = sae_out.new_tensor(0.0)
+
+        return ForwardOutput(sae_out, top_acts, top_indices, fvu, auxk_loss, multi_topk_fvu)
+
+    @torch.no_grad()
+    def set_decoder_norm_to_unit_norm(self):
+        """sparse_coder.py:273-279, one fused pass over W_dec."""
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        ops.unit_norm_rows_(self.W_dec.data)
+        torch.autograd.graph.increment_version(self.W_dec)
+
+    @torch.no_grad()
+    def remove_gradient_parallel_to_decoder_directions(self):
+        """sparse_coder.py:281-295, one fused pass over (W_dec.grad, W_dec)."""
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        assert self.W_dec.grad is not None
+        ops.remove_parallel_grad_(self.W_dec.grad, self.W_dec.data)
+
+
+def _natural_key(s: str):
+    import re
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
+
+
+# Allow for alternate naming conventions
+Sae = SparseCoder

@@ -1,0 +1,56 @@
+"""Sparse decoder dispatch with the reference's seam (sparsify/utils.py:81-103):
+``decoder_impl(top_indices, top_acts, W_dec_T)``. There is exactly one implementation,
+the HIP gather / segmented-reduction pair; nothing here falls back to torch."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+class SparseDecode(torch.autograd.Function):
+    """Counterpart of xFormersEmbeddingBag (sparsify/xformers.py:188-209)."""
+
+    @staticmethod
+    def forward(ctx, indices: Tensor, weight: Tensor, per_sample_weights: Tensor, bias: Tensor | None = None):
+        ops.forget_segments(indices)
+        w = weight.detach()
+        out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
+                                       None if bias is None else bias.detach())
+        ctx.save_for_backward(indices, weight, per_sample_weights)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gradient):
+        indices, weight, psw = ctx.saved_tensors
+        g = gradient.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        need_w, need_a = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gW = gA = gB = None
+        if need_w or need_a:
+            seg = ops.cached_segments(indices, weight.shape[0])
+            gW, _, gA = ops.segmented_weight_grad(seg, psw.detach().contiguous(), g, weight.detach(),
+                                                  want_dcoeff=need_a)
+            if gA is not None and gA.dtype != psw.dtype:
+                gA = gA.to(psw.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gB = ops.colsum(g)
+        return None, gW, gA, gB
+
+
+def hip_decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor) -> Tensor:
+    """Called as decoder_impl(top_indices, top_acts, self.W_dec.mT) (sparse_coder.py:201);
+    like both reference implementations it transposes back, so the table is (M, D)."""
+    table = W_dec.mT
+    if not table.is_contiguous():
+        table = table.contiguous()
+    idx = top_indices.reshape(-1, top_indices.shape[-1])
+    acts = top_acts.reshape(-1, top_acts.shape[-1])
+    out = SparseDecode.apply(idx.contiguous(), table, acts)
+    return out.reshape(*top_indices.shape[:-1], table.shape[1])
+
+
+decoder_impl = hip_decode

@@ -1,0 +1,296 @@
+"""GPU parity tests, kernel by kernel: HIP path (through the C ABI) vs the CPU oracle on the
+same seeded inputs. Integer/index results must be bit-exact; floating point tolerances are
+written next to each assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+def sort_by_index(vals, idx):
+    order = idx.argsort(dim=-1)
+    return vals.gather(-1, order), idx.gather(-1, order)
+
+
+# ------------------------------------------------------------------ encoder GEMM
+@pytest.mark.parametrize("N,D,M", [(64, 48, 384), (128, 64, 512), (100, 72, 200), (257, 256, 1000),
+                                    (512, 768, 1536), (300, 4096, 640)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_encoder_preacts(device, N, D, M, dtype):
+    from sparsify_amd import ops
+    if dtype == "bf16" and D % 8:
+        pytest.skip("bf16 path needs D % 8 == 0")
+    torch.manual_seed(N + D + M)
+    x = torch.randn(N, D)
+    W = torch.randn(M, D) / D**0.5
+    b = torch.randn(M) * 0.1
+    if dtype == "bf16":
+        xb, Wb, bb = x.bfloat16(), W.bfloat16(), b.bfloat16()
+        got = ops.encoder_preacts(dev(xb), dev(Wb), dev(bb)).cpu()
+        assert got.dtype == torch.bfloat16
+        # exact reference of the bf16 operands in fp64, then one rounding to bf16
+        exact = (xb.double() @ Wb.double().T + bb.double()).clamp_min(0)
+        # fp32 accumulation + a single bf16 rounding: within 1 bf16 ulp (2^-8 relative)
+        torch.testing.assert_close(got.double(), exact, rtol=2**-7, atol=1e-3)
+        ref = O.pre_activations(x, W, b, True)
+        mism = (got != ref).float().mean().item()
+        assert mism < 0.02, f"{mism:.4f} of bf16 outputs differ from the CPU bf16 linear"
+        raw = ops.encoder_preacts(dev(xb), dev(Wb), None, relu=False).cpu()
+        assert (raw < 0).any()
+    else:
+        got = ops.encoder_preacts(dev(x), dev(W), dev(b)).cpu()
+        exact = (x.double() @ W.double().T + b.double()).clamp_min(0)
+        # exact-fp32 MFMA chain over D terms
+        torch.testing.assert_close(got.double(), exact, rtol=1e-5, atol=2e-6 * D**0.5)
+
+
+# ------------------------------------------------------------------ top-k
+def check_topk(pre_cpu, k, vals, idx, keep=None):
+    """Set semantics of torch.topk: selected values are the k largest, indices are valid,
+    distinct and point at the returned values; ties may differ in index only."""
+    N, M = pre_cpu.shape
+    vals, idx = vals.cpu(), idx.cpu()
+    assert idx.dtype == torch.int64 and idx.shape == (N, k)
+    assert int(idx.min()) >= 0 and int(idx.max()) < M
+    assert (idx.sort(-1).values.diff(dim=-1) > 0).all(), "duplicate index in a row"
+    masked = pre_cpu.float()
+    if keep is not None:
+        masked = torch.where(keep[None], masked, torch.tensor(-torch.inf))
+    torch.testing.assert_close(vals.float(), masked.gather(1, idx), rtol=0, atol=0)
+    ref_vals = masked.topk(k, dim=-1).values
+    torch.testing.assert_close(vals.float().sort(-1, descending=True).values, ref_vals, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,M,k", [(7, 384, 10), (5, 512, 16), (3, 1000, 32), (4, 4096, 32), (2, 24576, 32),
+                                    (3, 131072, 192), (2, 2051, 7), (2, 6000, 1500), (2, 300, 300), (1, 262144, 768)])
+def test_topk_random(device, dtype, N, M, k):
+    from sparsify_amd import ops
+    torch.manual_seed(M + k)
+    pre = torch.randn(N, M).clamp_min(0).to(dtype)
+    vals, idx = ops.topk(dev(pre), k)
+    check_topk(pre, k, vals, idx)
+    if dtype == torch.float32:
+        # distinct values almost surely among the positives: index sets must match torch exactly
+        ref = pre.topk(k, dim=-1)
+        pos = ref.values.min(-1).values > 0
+        got_sorted = idx.cpu().sort(-1).values
+        assert torch.equal(got_sorted[pos], ref.indices.sort(-1).values[pos])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_topk_ties_and_degenerate_rows(device, dtype):
+    from sparsify_amd import ops
+    M, k = 8192, 64
+    rows = [
+        torch.zeros(M),                                            # all equal
+        torch.cat([torch.arange(10.0) + 1, torch.zeros(M - 10)]),  # fewer than k positive
+        torch.arange(M, dtype=torch.float32),                      # ascending (worst case for the bound)
+        torch.arange(M, 0, -1, dtype=torch.float32),               # descending
+        torch.full((M,), 3.0),                                     # constant non-zero
+        torch.randint(0, 4, (M,)).float(),                         # heavy ties
+        -torch.rand(M),                                            # all negative (raw affine output)
+    ]
+    pre = torch.stack(rows).to(dtype)
+    vals, idx = ops.topk(dev(pre), k)
+    check_topk(pre, k, vals, idx)
+    # deterministic tie rule: lowest indices win
+    assert torch.equal(idx[0].cpu().sort().values, torch.arange(k))
+    # repeatability (bitwise)
+    v2, i2 = ops.topk(dev(pre), k)
+    assert torch.equal(v2, vals) and torch.equal(i2, idx)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,k,frac", [(4096, 24, 0.33), (4096, 2048, 0.33), (24576, 384, 0.1), (512, 100, 0.1)])
+def test_topk_masked_auxk(device, dtype, M, k, frac):
+    """where(dead_mask, pre, -inf).topk(k_aux) -- sparse_coder.py:240-243."""
+    from sparsify_amd import ops
+    torch.manual_seed(M + k)
+    pre = torch.randn(6, M).clamp_min(0).to(dtype)
+    keep = torch.rand(M) < frac
+    vals, idx = ops.topk(dev(pre), k, keep_mask=dev(keep))
+    check_topk(pre, k, vals, idx, keep)
+    if int(keep.sum()) >= k:
+        assert keep[idx.cpu()].all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groupmax(device, dtype):
+    from sparsify_amd import ops
+    torch.manual_seed(3)
+    for N, M, k in [(9, 384, 12), (4, 512, 16), (3, 4096, 32), (2, 24576, 192)]:
+        pre = torch.randn(N, M).clamp_min(0).to(dtype)
+        vals, idx = ops.groupmax(dev(pre), k)
+        rv, ri = O.select_latents(pre.float(), k, "groupmax")
+        assert torch.equal(idx.cpu(), ri)
+        torch.testing.assert_close(vals.cpu().float(), rv, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------ gathers
+@pytest.mark.parametrize("N,k,M,D", [(2, 10, 128, 48), (2, 10, 128, 64), (96, 24, 640, 200), (33, 7, 100, 50),
+                                      (64, 192, 4096, 4096), (5, 3, 17, 1028)])
+@pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
+def test_gather_rows_weighted(device, N, k, M, D, cdtype):
+    from sparsify_amd import ops
+    torch.manual_seed(D)
+    table = torch.randn(M, D)
+    idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
+    coeff = torch.randn(N, k).to(cdtype)
+    bias = torch.randn(D)
+    got = ops.gather_rows_weighted(dev(idx), dev(coeff), dev(table), dev(bias)).cpu()
+    ref = O.gather_sum(idx, coeff.float(), table) + bias
+    # fp32 fma chain of k terms vs the oracle's mul+add chain
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5 * k**0.5)
+    got2 = ops.gather_rows_weighted(dev(idx), dev(coeff), dev(table), None).cpu()
+    torch.testing.assert_close(got2, ref - bias, rtol=1e-5, atol=1e-5 * k**0.5)
+
+
+# ------------------------------------------------------------------ segments
+@pytest.mark.parametrize("N,k,M", [(2, 10, 128), (96, 24, 640), (1000, 32, 24576), (300, 192, 131072),
+                                    (17, 5, 7), (64, 16, 1 << 20), (4096, 32, 2049)])
+def test_latent_segments_bit_exact(device, N, k, M):
+    from sparsify_amd import ops
+    torch.manual_seed(N + k)
+    if k <= M:
+        idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)]) if M < 5000 else torch.randint(0, M, (N, k))
+    else:
+        idx = torch.randint(0, M, (N, k))
+    if M > 100:
+        idx[:, 0] = 5          # one very long segment
+    seg = ops.build_latent_segments(dev(idx), M)
+    flat = idx.reshape(-1).numpy()
+    ref_perm = np.argsort(flat, kind="stable").astype(np.int64)
+    counts = np.bincount(flat, minlength=M)
+    ref_begin = np.concatenate([[0], np.cumsum(counts)])
+    perm = seg.perm.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(perm, ref_perm)
+    assert np.array_equal(seg.seg_begin.cpu().numpy().astype(np.int64), ref_begin)
+
+
+@pytest.mark.parametrize("N,k,M,D", [(2, 10, 128, 48), (96, 24, 640, 200), (256, 32, 2048, 1024),
+                                      (128, 16, 512, 2048), (64, 48, 1024, 4096), (40, 8, 64, 8200)])
+@pytest.mark.parametrize("rdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
+def test_segmented_weight_grad(device, N, k, M, D, rdtype, cdtype):
+    from sparsify_amd import ops
+    torch.manual_seed(N + D)
+    idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
+    for n in range(N // 2):                                # a long segment, rows stay distinct
+        if 3 not in idx[n]:
+            idx[n, 0] = 3
+    coeff = torch.randn(N, k).to(cdtype)
+    rows = torch.randn(N, D).to(rdtype)
+    W = torch.randn(M, D)
+    seg = ops.build_latent_segments(dev(idx), M)
+    gW, gb, dc = ops.segmented_weight_grad(seg, dev(coeff), dev(rows), dev(W), want_bias=True, want_dcoeff=True)
+    ref_gW = O.scatter_rows(idx, coeff.float(), rows.float(), M)
+    ref_gb = O.scatter_scalar(idx, coeff.float(), M)
+    ref_dc = torch.einsum("nd,nsd->ns", rows.float(), W[idx])
+    # fp32 sums of <= N/2 terms (segment) / D terms (dot), different order than the oracle
+    torch.testing.assert_close(gW.cpu(), ref_gW, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gb.cpu(), ref_gb, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dc.cpu(), ref_dc, rtol=1e-4, atol=1e-4 * D**0.5)
+    # bitwise reproducible
+    gW2, gb2, dc2 = ops.segmented_weight_grad(seg, dev(coeff), dev(rows), dev(W), want_bias=True, want_dcoeff=True)
+    assert torch.equal(gW, gW2) and torch.equal(gb, gb2) and torch.equal(dc, dc2)
+    # every row written: empty segments are exact zeros
+    empty = torch.ones(M, dtype=torch.bool)
+    empty[idx.reshape(-1)] = False
+    assert (gW.cpu()[empty] == 0).all()
+
+
+# ------------------------------------------------------------------ loss pieces
+@pytest.mark.parametrize("N,D", [(64, 48), (128, 64), (1000, 200), (513, 4096), (37, 50)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_reductions(device, N, D, dtype):
+    from sparsify_amd import ops
+    torch.manual_seed(N)
+    y = (torch.randn(N, D) + torch.randn(D)).to(dtype)
+    p = torch.randn(N, D)
+    tv = ops.total_variance(dev(y)).cpu()
+    yd = y.double()
+    torch.testing.assert_close(tv.double()[0], (yd - yd.mean(0)).pow(2).sum(), rtol=2e-5, atol=0)
+    e, sq = ops.residual_sumsq(dev(y), dev(p))
+    torch.testing.assert_close(e.cpu(), y.float() - p, rtol=0, atol=0)
+    torch.testing.assert_close(sq.cpu().double()[0], (yd - p.double()).pow(2).sum(), rtol=2e-5, atol=0)
+    cs = ops.colsum(dev(y), 1.0 / N).cpu()
+    torch.testing.assert_close(cs.double(), yd.mean(0), rtol=1e-5, atol=1e-6)
+    num = torch.tensor([3.0]); den = torch.tensor([7.0])
+    sc = ops.scale_by_ratio(e, -2.0, dev(num), dev(den)).cpu()
+    torch.testing.assert_close(sc, e.cpu() * (-2.0 * 3.0 / 7.0), rtol=1e-6, atol=0)
+    v = torch.randn(N)
+    if dtype == torch.float32:
+        vm = ops.vec_mat(dev(v), dev(y), -1.0).cpu()
+        torch.testing.assert_close(vm.double(), -(v.double() @ yd), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ dense updates (golden: real reference)
+def test_dense_updates_vs_reference_golden(device):
+    from conftest import load_golden
+    from sparsify_amd import ops
+    g = load_golden("dense_ops")
+    W = dev(g["W0"].clone())
+    ops.unit_norm_rows_(W)
+    torch.testing.assert_close(W.cpu(), g["W1"], rtol=1e-6, atol=1e-7)
+    G = dev(g["G0"].clone())
+    ops.remove_parallel_grad_(G, dev(g["W1"]))
+    torch.testing.assert_close(G.cpu(), g["G1"], rtol=1e-5, atol=1e-6)
+    p = dev(g["p0"].clone())
+    shadow = torch.empty_like(p, dtype=torch.bfloat16)
+    for t in range(10):
+        ops.signsgd_step_(p, dev(g["grads"][t].contiguous()), g["lr"], shadow)
+        if t == 0:
+            torch.testing.assert_close(p.cpu(), g["p1"], rtol=0, atol=1e-7)
+    torch.testing.assert_close(p.cpu(), g["p10"], rtol=0, atol=1e-6)
+    assert torch.equal(shadow.cpu(), p.cpu().bfloat16())
+    # fused projected-gradient + sign step == the two reference steps
+    W2 = dev(g["W1"].clone())
+    ops.decoder_project_signsgd_(W2, dev(g["G0"]), 1e-3)
+    ref = O.signsgd_update(g["W1"], g["G1"], 1e-3)
+    # sign() of a projected component that is ~0 may flip; everything else is exact
+    bad = (W2.cpu() - ref).abs() > 1e-7
+    assert bad.float().mean() < 1e-3
+    assert (g["G1"][bad].abs() < 1e-5).all()
+
+
+def test_dead_latent_bookkeeping(device):
+    from sparsify_amd import ops
+    M = 1000
+    torch.manual_seed(0)
+    counts = torch.randint(0, 50, (M,), dtype=torch.int64)
+    fired = torch.zeros(M, dtype=torch.bool)
+    idx = torch.randint(0, M, (64, 8))
+    d_counts, d_fired = dev(counts.clone()), dev(fired.clone())
+    ops.mark_fired_(d_fired, dev(idx))
+    ref_fired = fired.clone(); ref_fired[idx.flatten()] = True           # trainer.py:422
+    assert torch.equal(d_fired.cpu(), ref_fired)
+    ops.dead_counter_step_(d_counts, d_fired, 512)
+    ref_counts = counts + 512; ref_counts[ref_fired] = 0                 # trainer.py:531-533
+    assert torch.equal(d_counts.cpu(), ref_counts)
+    assert not d_fired.any()                                             # trainer.py:537-538
+    mask, n_dead = ops.dead_mask(d_counts, 530)
+    assert torch.equal(mask.cpu(), ref_counts > 530)                     # trainer.py:415
+    assert int(n_dead.item()) == int((ref_counts > 530).sum())
+
+
+def test_center_cast(device):
+    from sparsify_amd import ops
+    torch.manual_seed(1)
+    for N, D in [(5, 48), (33, 50), (64, 4096)]:
+        for dt in (torch.float32, torch.bfloat16):
+            x = torch.randn(N, D).to(dt)
+            b = torch.randn(D)
+            f, h = ops.center_cast(dev(x), dev(b), True, True)
+            ref = x - b                       # promotes to fp32 like sparse_coder.py:192
+            assert torch.equal(f.cpu(), ref)
+            assert torch.equal(h.cpu(), ref.bfloat16())
+    w = torch.randn(1000, 3)
+    assert torch.equal(ops.cast_bf16(dev(w)).cpu(), w.bfloat16())
