@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: SAE train tokens/s at d_in=4096, 131072 latents, k=192 (BASELINE.json
+configs[2], the configuration the metric is quoted on), bf16 autocast over fp32 parameters,
+synthetic activations, plain SignSGD, one process per GPU (DDP over tokens via RCCL for N>1).
+
+A step is one full Trainer micro-step + step tail (sparsify/trainer.py:340-447, 510-538):
+decoder re-normalisation, encode (bf16 MFMA GEMM + top-k), sparse decode, FVU, backward
+(segmented weight gradients), gradient all-reduce (N>1), projected gradient + SignSGD,
+dead-latent counters. Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: Llama-3-8B layer shape
+    "llama3-8b-layer d_in=4096 M=131072 k=192": dict(d_in=4096, num_latents=131072, k=192),
+    # BASELINE.json configs[0] (CPU-runnable reference case), for quick checks
+    "gpt2-small d_in=768 M=24576 k=32": dict(d_in=768, num_latents=24576, k=32),
+}
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s
+
+
+def cpu_baseline(w: dict, tokens: int, budget_s: float = 25.0) -> dict:
+    """The CPU oracle (a restatement of the reference's torch path, pinned to it by golden
+    vectors) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import sae_oracle as O
+
+    torch.manual_seed(0)
+    D, M, k = w["d_in"], w["num_latents"], w["k"]
+    P = O.init_params(D, M, seed=0)
+    cfg = O.OracleConfig(k=k)
+    lr = O.signum_lr(M)
+    g = torch.Generator().manual_seed(0)
+    offset = torch.randn(D, generator=g)
+    times = []
+    t_begin = time.perf_counter()
+    step = 0
+    while True:
+        gs = torch.Generator().manual_seed(1000 + step)
+        x = torch.randn(tokens, D, generator=gs) + offset
+        t0 = time.perf_counter()
+        O.train_step_signsgd(P, x, None, cfg, lr, step=step, bf16=False)
+        dt = time.perf_counter() - t0
+        if step > 0:
+            times.append(dt)
+        step += 1
+        if (time.perf_counter() - t_begin > budget_s and len(times) >= 2) or len(times) >= 10:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": tokens / med, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} fp32 steps of {tokens} tokens, same shapes/init/optimizer; "
+                      f"the reference's (N*k,D) fp32 temporary forbids the GPU batch size on CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=16384, help="tokens per GPU per step")
+    ap.add_argument("--workload", default="llama3-8b-layer d_in=4096 M=131072 k=192", choices=list(WORKLOADS))
+    ap.add_argument("--cpu-tokens", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="fp32 activations / no autocast (not the headline)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from sparsify_amd import SparseCoderConfig, TrainConfig, ops
+    from sparsify_amd.trainer import SyntheticActivations, Trainer
+
+    w = WORKLOADS[args.workload]
+    N, D, M, k = args.tokens, w["d_in"], w["num_latents"], w["k"]
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["layers.10"],
+                      save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False)
+    total = args.warmup + args.steps
+    src = SyntheticActivations(["layers.10"], D, N, total, device=device,
+                               dtype=torch.float32 if args.fp32 else torch.bfloat16, rank=rank)
+    trainer = Trainer(cfg, src, device=device)
+    sae = trainer.saes["layers.10"]
+    if args.fp32:
+        fwd = type(sae).forward.__wrapped__
+        type(sae).forward = lambda self, *a, **kw: _fp32_forward(fwd, self, *a, **kw)
+    batches = [src.batch(s) for s in range(total)]        # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        trainer.train_micro_batch(batches[s])
+    barrier()
+    ops.timer.enabled = True
+    ops.timer.reset()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        trainer.train_micro_batch(batches[s])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.timer.enabled = False
+    kern = ops.timer.summary()
+    fvu = float(trainer._metrics["fvu/layers.10"].item()) * cfg.wandb_log_frequency / max(total, 1)
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        gemm = kern["sphip_encoder_preacts"]
+        flops = 2.0 * N * D * M                                   # algorithmic FLOP per launch
+        tflops = flops / (gemm["mean_ms"] * 1e-3) / 1e12
+        dec = kern["sphip_gather_rows_weighted"]
+        wg = kern["sphip_segmented_weight_grad"]
+        gather_bytes = N * (k * D * 4 + D * 4)                    # decode fwd per token
+        out = {
+            "metric": "SAE train tokens/sec at d=4096, M=131072, k=192 (1-8 GPUs); MFMA util %",
+            "value": N * world * args.steps / elapsed,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.fp32 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": "signsgd",
+                       "params": "fp32", "parallelism": f"dp{world}", "mean_fvu": fvu},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "encoder_gemm_kernel (sphip_encoder_preacts)", "ms": gemm["mean_ms"]},
+            "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in kern.items()},
+            "hbm_kernels": {
+                "decode_gather_GBs": gather_bytes / (dec["total_ms"] / dec["calls"] * 1e-3) / 1e9,
+                "segmented_wgrad_GBs": 2 * N * k * D * 4 / (wg["total_ms"] / args.steps * 1e-3) / 1e9,
+                "peak_GBs": HBM_PEAK_GBS,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_tokens)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _fp32_forward(fwd, self, *a, **kw):
+    with torch.autocast("cuda", enabled=False):
+        return fwd(self, *a, **kw)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,40 @@ def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing on the launching stream (bench.py's roofline
+    numbers). Disabled by default: no events, no overhead."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events: dict[str, list] = {}
+
+    def start(self, name: str, t: Tensor):
+        if not self.enabled:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(t.device))
+        self.events.setdefault(name, []).append(ev)
+        return ev
+
+    def stop(self, ev, t: Tensor):
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(t.device))
+
+    def summary(self) -> dict[str, dict]:
+        """name -> {calls, mean_ms, total_ms}; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"calls": len(ms), "mean_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+    def reset(self):
+        self.events = {}
+
+
+timer = KernelTimer()
+
 _workspaces: dict[tuple, Tensor] = {}
 
 
@@ -90,8 +124,10 @@ def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True
     if W.shape[1] != D or (bias is not None and bias.shape[0] != M):
         raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(W.shape)}")
     pre = torch.empty(N, M, dtype=x.dtype, device=x.device)
+    _ev = timer.start("sphip_encoder_preacts", x)
     check(_lib.load().sphip_encoder_preacts(x.data_ptr(), W.data_ptr(), _ptr(bias), pre.data_ptr(), _dt(x), N, D, M,
                                            int(relu), _stream(x)), "sphip_encoder_preacts")
+    timer.stop(_ev, x)
     return pre
 
 
@@ -107,8 +143,10 @@ def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None):
             raise ValueError("keep_mask must be a (M,) bool/uint8 tensor")
     vals = torch.empty(N, k, dtype=pre.dtype, device=pre.device)
     idx = torch.empty(N, k, dtype=torch.int64, device=pre.device)
+    _ev = timer.start("sphip_topk", pre)
     check(_lib.load().sphip_topk(pre.data_ptr(), _dt(pre), _ptr(keep_mask), N, M, k, vals.data_ptr(), idx.data_ptr(),
                                 _stream(pre)), "sphip_topk")
+    timer.stop(_ev, pre)
     return vals, idx
 
 
@@ -135,9 +173,11 @@ def gather_rows_weighted(idx: Tensor, coeff: Tensor, table: Tensor, bias: Tensor
     if coeff.shape != idx.shape:
         raise ValueError(f"coeff {tuple(coeff.shape)} vs indices {tuple(idx.shape)}")
     out = torch.empty(N, D, dtype=torch.float32, device=table.device)
+    _ev = timer.start("sphip_gather_rows_weighted", table)
     check(_lib.load().sphip_gather_rows_weighted(idx.data_ptr(), coeff.data_ptr(), _dt(coeff), table.data_ptr(),
                                                 _ptr(bias), out.data_ptr(), N, k, M, D, _stream(table)),
           "sphip_gather_rows_weighted")
+    timer.stop(_ev, table)
     return out
 
 
@@ -158,8 +198,10 @@ def build_latent_segments(idx: Tensor, M: int) -> LatentSegments:
     ws = _workspace(idx.device, nbytes, "segments")
     perm = torch.empty(N * k, dtype=torch.int32, device=idx.device)       # holds uint32 entry ids
     seg = torch.empty(M + 1, dtype=torch.int32, device=idx.device)
+    _ev = timer.start("sphip_build_latent_segments", idx)
     check(lib.sphip_build_latent_segments(idx.data_ptr(), N, k, M, perm.data_ptr(), seg.data_ptr(), ws.data_ptr(),
                                           ws.numel(), _stream(idx)), "sphip_build_latent_segments")
+    timer.stop(_ev, idx)
     return LatentSegments(perm, seg, N, k, M)
 
 
@@ -207,10 +249,12 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
     gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
     gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
     dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
+    _ev = timer.start("sphip_segmented_weight_grad", rows)
     check(_lib.load().sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
                                                  _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
                                                  gW.data_ptr(), _ptr(gb), _ptr(dc), N, k, M, D, _stream(rows)),
           "sphip_segmented_weight_grad")
+    timer.stop(_ev, rows)
     return gW, gb, dc
 
 

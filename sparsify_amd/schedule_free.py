@@ -1,0 +1,108 @@
+"""Schedule-free wrapper around a base optimizer (used for the reference's default
+``optimizer="signum"``: ScheduleFreeWrapper(SignSGD, momentum=0.95), trainer.py:146-162).
+
+PARITY UNPINNED: the reference takes this class from the third-party package
+``schedulefree`` (unpinned in its pyproject.toml, not vendored, absent from this image and
+untouched by any reference test). This file restates the published schedule-free wrapper
+algorithm (Defazio et al., "The Road Less Scheduled", 2024):
+
+    z : the base optimizer's iterate        x : the running average (evaluation point)
+    y = (1 - beta) z + beta x               : where gradients are taken (train mode)
+
+    step:  y -> x (undo the interpolation), base optimizer steps on z,
+           x <- (1 - c) x + c z   with  c = w / sum(w),  w = lr_max ** weight_lr_power,
+           parameter <- y = beta x + (1 - beta) z
+    eval(): parameter <- x          train(): parameter <- y
+"""
+from __future__ import annotations
+
+import torch
+
+
+class ScheduleFreeWrapper:
+    def __init__(self, base: torch.optim.Optimizer, momentum: float = 0.9, weight_lr_power: float = 2.0,
+                 r: float = 0.0):
+        self.base = base
+        self.momentum = momentum
+        self.weight_lr_power = weight_lr_power
+        self.r = r
+        self.train_mode = False
+        for group in self.param_groups:
+            group.setdefault("k", 0)
+            group.setdefault("weight_sum", 0.0)
+            group.setdefault("lr_max", 0.0)
+
+    @property
+    def param_groups(self):
+        return self.base.param_groups
+
+    @property
+    def state(self):
+        return self.base.state
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.base.zero_grad(set_to_none)
+
+    def state_dict(self):
+        return {"base": self.base.state_dict(), "train_mode": self.train_mode}
+
+    def load_state_dict(self, sd):
+        self.base.load_state_dict(sd["base"])
+        self.train_mode = sd["train_mode"]
+
+    @torch.no_grad()
+    def eval(self):
+        if self.train_mode:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state[p]
+                    if "z" in st:
+                        p.lerp_(st["z"], 1 - 1 / self.momentum)      # y -> x
+            self.train_mode = False
+
+    @torch.no_grad()
+    def train(self):
+        if not self.train_mode:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state[p]
+                    if "z" in st:
+                        p.lerp_(st["z"], 1 - self.momentum)          # x -> y
+            self.train_mode = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self.train_mode:
+            raise RuntimeError("call .train() on the schedule-free optimizer before stepping")
+        swapped = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if "z" not in st:
+                    st["z"] = p.detach().clone(memory_format=torch.preserve_format)
+                z = st["z"]
+                p.lerp_(z, 1 - 1 / self.momentum)        # y -> x
+                # let the base optimizer act on z: exchange the contents of p and z
+                tmp = p.detach().clone()
+                p.copy_(z)
+                z.copy_(tmp)                             # z now holds x
+                swapped.append((group, p))
+        self.base.step()
+        for group in self.param_groups:
+            lr = group["lr"] * group.get("d", 1.0)
+            group["lr_max"] = max(lr, group["lr_max"])
+            weight = ((group["k"] + 1) ** self.r) * (group["lr_max"] ** self.weight_lr_power)
+            group["weight_sum"] += weight
+            c = weight / group["weight_sum"] if group["weight_sum"] > 0 else 0.0
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                x = self.state[p]["z"]                   # holds x since the exchange
+                z_new = p.detach().clone()
+                p.copy_(x)                               # p = x
+                self.state[p]["z"].copy_(z_new)          # z = stepped z
+                p.lerp_(self.state[p]["z"], c)           # x <- (1-c) x + c z
+                p.lerp_(self.state[p]["z"], 1 - self.momentum)    # -> y
+            group["k"] += 1

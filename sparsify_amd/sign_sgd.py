@@ -23,10 +23,17 @@ class SignSGD(Optimizer):
         assert closure is None, "Closure is not supported."
         for group in self.param_groups:
             lr = group["lr"]
+            project = group.get("project_rows", False)
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if project:
+                    # decoder matrix: remove_gradient_parallel_to_decoder_directions
+                    # (sparse_coder.py:281-295) fused with the sign step, one pass over (W, G)
+                    ops.decoder_project_signsgd_(p.data, g, lr)
+                    torch.autograd.graph.increment_version(p)
+                    continue
                 shadow = peek_bf16_shadow(p)
                 ops.signsgd_step_(p.data, g, lr, shadow)
                 torch.autograd.graph.increment_version(p)

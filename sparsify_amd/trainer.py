@@ -1,0 +1,464 @@
+"""Trainer: the reference's per-hookpoint train-step driver (sparsify/trainer.py:340-447, the
+hook body) and step tail (:510-538) as a host loop over activation batches.
+
+What is kept from the reference: the TrainConfig fields, step-0 bias init, per-call decoder
+re-normalisation, loss = fvu + alpha*auxk + multi_topk/8 divided by acc steps, projected
+gradient, optimizer/LR rules, k-decay, dead-latent counters, DDP / distribute_modules
+semantics, checkpoint layout. What is not here (out of scope): running
+a HuggingFace model to produce the activations -- the Trainer consumes an
+``ActivationSource`` (any iterable of {hookpoint: outputs | (inputs, outputs)} batches).
+
+MI355X-first differences, all value-preserving:
+  * gradients are all-reduced (RCCL) once per optimizer step, launched from
+    post-accumulate hooks so W_dec.grad's transfer overlaps the encoder backward, instead of
+    DDP's all-reduce on every micro-step backward (trainer.py:457-468 has no no_sync());
+  * logged scalars stay on the device until they are logged (the reference calls float()
+    on three all-reduced scalars per hook call, trainer.py:433-441);
+  * with plain SignSGD the projected gradient and the sign step of W_dec are one kernel.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import defaultdict
+from pathlib import Path
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops
+from .config import TrainConfig
+from .muon import Muon
+from .schedule_free import ScheduleFreeWrapper
+from .sign_sgd import SignSGD
+from .sparse_coder import SparseCoder
+
+
+class SyntheticActivations:
+    """Seeded synthetic activation batches: x = randn(N, D) + offset(D),
+    fresh batch per step (seed 1000 + step); transcoder target y = x @ R + 0.1 randn."""
+
+    def __init__(self, hookpoints: list[str], d_in: int, tokens_per_batch: int, num_batches: int, *,
+                 device="cuda", dtype=torch.bfloat16, transcode: bool = False, rank: int = 0, seed: int = 0):
+        self.hookpoints, self.d_in, self.n, self.num_batches = list(hookpoints), d_in, tokens_per_batch, num_batches
+        self.device, self.dtype, self.transcode, self.rank = torch.device(device), dtype, transcode, rank
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        self.offset = torch.randn(d_in, device=self.device, generator=g)
+        self.R = torch.randn(d_in, d_in, device=self.device, generator=g) / d_in**0.5 if transcode else None
+        self.widths = {h: d_in for h in self.hookpoints}
+
+    def __len__(self):
+        return self.num_batches
+
+    def batch(self, step: int) -> dict:
+        out = {}
+        for i, h in enumerate(self.hookpoints):
+            g = torch.Generator(device=self.device).manual_seed((1000 + step) * 9973 + 131 * self.rank + i)
+            x = torch.randn(self.n, self.d_in, device=self.device, generator=g) + self.offset
+            if self.transcode:
+                y = x @ self.R + 0.1 * torch.randn(self.n, self.d_in, device=self.device, generator=g)
+                out[h] = (x.to(self.dtype), y.to(self.dtype))
+            else:
+                out[h] = x.to(self.dtype)
+        return out
+
+    def __iter__(self):
+        for s in range(self.num_batches):
+            yield self.batch(s)
+
+
+class Trainer:
+    def __init__(self, cfg: TrainConfig, source, *, device: str | torch.device = "cuda",
+                 saes: dict[str, SparseCoder] | None = None):
+        """``source``: iterable (with ``widths`` and ``__len__``) of micro-batches, each a dict
+        hookpoint -> outputs (N,D) for autoencoders or (inputs, outputs) for transcoders."""
+        self.cfg = cfg
+        self.source = source
+        self.device = torch.device(device)
+        if not cfg.hookpoints:
+            cfg.hookpoints = list(source.widths)
+        cfg.hookpoints = cfg.hookpoints[:: cfg.layer_stride]
+        self.distribute_modules()
+
+        widths = source.widths
+        if cfg.distribute_modules and len({widths[h] for h in cfg.hookpoints}) > 1:
+            raise ValueError("All modules must output tensors of the same shape when using "
+                             f"`distribute_modules=True`, got {set(widths.values())}")
+
+        # trainer.py:76-87: one fp32 SAE per local hookpoint (and seed)
+        self.saes: dict[str, SparseCoder] = {}
+        if saes is not None:
+            self.saes = dict(saes)
+        else:
+            for hook in self.local_hookpoints():
+                for seed in cfg.init_seeds:
+                    torch.manual_seed(seed)
+                    name = f"{hook}/seed{seed}" if len(cfg.init_seeds) > 1 else hook
+                    self.saes[name] = SparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
+
+        num_batches = max(len(source) // max(cfg.batch_size, 1), 1) if hasattr(source, "__len__") else 1
+        self._build_optimizers(num_batches)
+
+        self.global_step = 0
+        self.num_tokens_since_fired = {
+            name: torch.zeros(sae.num_latents, device=self.device, dtype=torch.long)
+            for name, sae in self.saes.items()
+        }
+        self.did_fire = {
+            name: torch.zeros(sae.num_latents, device=self.device, dtype=torch.bool)
+            for name, sae in self.saes.items()
+        }
+        first = next(iter(self.saes.values()))
+        self.initial_k = min(first.num_latents, round(first.d_in * 10))       # trainer.py:176-177
+        self.final_k = cfg.sae.k
+        self.best_loss = {name: float("inf") for name in self.local_hookpoints()}
+        self.num_tokens_in_step = 0
+        self._metrics = defaultdict(lambda: torch.zeros((), device=self.device))
+        self._pending: list = []
+        self._hooks_installed = False
+        self.last_logged: dict = {}
+
+    # ------------------------------------------------------------------ optimizers (trainer.py:92-164)
+    def _build_optimizers(self, num_batches: int):
+        cfg = self.cfg
+        self.lr_schedulers = []
+        project = cfg.sae.normalize_decoder and not cfg.sae.transcode
+        self._fused_projection = False
+
+        def groups(default_lr):
+            return [dict(params=list(sae.parameters()), lr=cfg.lr or default_lr(sae)) for sae in self.saes.values()]
+
+        match cfg.optimizer:
+            case "adam":
+                pgs = groups(lambda s: 2e-4 / (s.num_latents / (2**14)) ** 0.5)
+                adam = torch.optim.Adam(pgs)
+                self.optimizers = [adam]
+                self.lr_schedulers = [_linear_warmup_decay(adam, cfg.lr_warmup_steps, num_batches)]
+            case "muon":
+                params = [p for sae in self.saes.values() for p in sae.parameters()]
+                muon_params = [p for p in params if p.ndim >= 2]
+                rest = [p for p in params if p.ndim < 2]
+                self.optimizers = [
+                    Muon(muon_params, lr=cfg.lr or 2e-3, ddp=not cfg.distribute_modules),
+                    torch.optim.Adam(rest, lr=cfg.lr or 2e-3),
+                ]
+                self.lr_schedulers = [
+                    _linear_warmup_decay(self.optimizers[0], 0, num_batches),
+                    _linear_warmup_decay(self.optimizers[1], cfg.lr_warmup_steps, num_batches),
+                ]
+            case "signum":
+                pgs = groups(lambda s: 5e-3 / (s.num_latents / (2**14)) ** 0.5)
+                opt = ScheduleFreeWrapper(SignSGD(pgs), momentum=0.95)
+                opt.train()
+                self.optimizers = [opt]
+            case "signsgd":
+                # plain SignSGD (sign_sgd.py) with the "signum" learning-rate rule; the fused
+                # projected-gradient + sign step handles W_dec in one pass
+                pgs = []
+                for sae in self.saes.values():
+                    lr = cfg.lr or 5e-3 / (sae.num_latents / (2**14)) ** 0.5
+                    dec = [sae.W_dec] if (project and sae.W_dec is not None) else []
+                    rest = [p for p in sae.parameters() if not any(p is d for d in dec)]
+                    if dec:
+                        pgs.append(dict(params=dec, lr=lr, project_rows=True))
+                    pgs.append(dict(params=rest, lr=lr))
+                self.optimizers = [SignSGD(pgs)]
+                self._fused_projection = project
+            case other:
+                raise ValueError(f"Unknown optimizer '{other}'")
+
+    # ------------------------------------------------------------------ k schedule (trainer.py:229-235)
+    def get_current_k(self) -> int:
+        if self.global_step >= self.cfg.k_decay_steps:
+            return self.final_k
+        progress = self.global_step / self.cfg.k_decay_steps
+        return round(self.initial_k * (1 - progress) + self.final_k * progress)
+
+    # ------------------------------------------------------------------ distributed helpers
+    @property
+    def ddp(self) -> bool:
+        return dist.is_initialized() and dist.get_world_size() > 1 and not self.cfg.distribute_modules
+
+    def maybe_all_reduce(self, x: Tensor, op: str = "mean") -> Tensor:
+        """trainer.py:614-628"""
+        if not dist.is_initialized() or self.cfg.distribute_modules or dist.get_world_size() == 1:
+            return x
+        if op == "sum":
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        elif op == "mean":
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+            x /= dist.get_world_size()
+        elif op == "max":
+            if x.dtype == torch.bool:
+                buf = x.view(torch.uint8)
+                dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+            else:
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        else:
+            raise ValueError(f"Unknown reduction op '{op}'")
+        return x
+
+    def distribute_modules(self):
+        """trainer.py:630-646: contiguous blocks of hookpoints per rank."""
+        if not self.cfg.distribute_modules:
+            self.module_plan = []
+            return
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        layers_per_rank, rem = divmod(len(self.cfg.hookpoints), world)
+        assert rem == 0, "Number of modules must be divisible by world size"
+        self.module_plan = [
+            self.cfg.hookpoints[start: start + layers_per_rank]
+            for start in range(0, len(self.cfg.hookpoints), layers_per_rank)
+        ]
+
+    def local_hookpoints(self) -> list[str]:
+        if self.module_plan:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            return self.module_plan[rank]
+        return self.cfg.hookpoints
+
+    def _install_grad_hooks(self):
+        """Overlap the dense-gradient all-reduce with the rest of the backward: each
+        parameter's all-reduce is launched (async, RCCL stream) as soon as its gradient has
+        been accumulated on the last micro-step of an optimizer step."""
+        if self._hooks_installed or not self.ddp:
+            return
+        world = dist.get_world_size()
+
+        def hook(p: Tensor):
+            if (self.global_step + 1) % self.cfg.grad_acc_steps != 0:
+                return
+            if dist.get_backend() == "nccl":
+                self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True))
+            else:
+                w = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True)
+                self._pending.append((w, p, world))
+
+        for sae in self.saes.values():
+            for p in sae.parameters():
+                p.register_post_accumulate_grad_hook(hook)
+        self._hooks_installed = True
+
+    def _finish_grad_reduce(self):
+        for item in self._pending:
+            if isinstance(item, tuple):
+                w, p, world = item
+                w.wait()
+                p.grad /= world
+            else:
+                item.wait()
+        self._pending.clear()
+
+    # ------------------------------------------------------------------ the hook body (trainer.py:340-447)
+    def train_on_activations(self, name: str, inputs: Tensor | None, outputs: Tensor, mask: Tensor | None = None):
+        cfg = self.cfg
+        hook_name = name.partition("/")[0]
+
+        if cfg.distribute_modules and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            gathered = outputs.new_empty(outputs.shape[0] * world, *outputs.shape[1:])
+            dist.all_gather_into_tensor(gathered, outputs.contiguous())
+            outputs = gathered
+            if cfg.sae.transcode:
+                gi = inputs.new_empty(inputs.shape[0] * world, *inputs.shape[1:])
+                dist.all_gather_into_tensor(gi, inputs.contiguous())
+                inputs = gi
+            if mask is not None:
+                gm = mask.new_empty(mask.shape[0] * world, *mask.shape[1:])
+                dist.all_gather_into_tensor(gm.view(torch.uint8), mask.contiguous().view(torch.uint8))
+                mask = gm
+            if hook_name not in self.module_plan[dist.get_rank()]:
+                return None
+
+        outputs = outputs.reshape(-1, outputs.shape[-1])
+        inputs = inputs.reshape(-1, inputs.shape[-1]) if cfg.sae.transcode else outputs
+        if mask is not None:
+            mask = mask.reshape(-1)
+            outputs = outputs[mask]
+            inputs = inputs[mask] if cfg.sae.transcode else outputs
+        n_tokens = outputs.shape[0]
+
+        raw = self.saes[name]
+        if self.global_step == 0 and not cfg.finetune:
+            # trainer.py:394-404: centre the pre-activations / initialise b_dec with the mean
+            if cfg.sae.transcode:
+                mean = self.maybe_all_reduce(ops.colsum(inputs.contiguous(), 1.0 / inputs.shape[0])).to(raw.dtype)
+                raw.encoder.bias.data = -mean @ raw.encoder.weight.data.T
+            mean = self.maybe_all_reduce(ops.colsum(outputs.contiguous(), 1.0 / outputs.shape[0]))
+            raw.b_dec.data = mean.to(raw.dtype)
+
+        if raw.cfg.normalize_decoder and not cfg.sae.transcode:
+            raw.set_decoder_norm_to_unit_norm()
+
+        dead_mask = None
+        if cfg.auxk_alpha > 0:
+            dead_mask, _ = ops.dead_mask(self.num_tokens_since_fired[name], cfg.dead_feature_threshold)
+
+        self._install_grad_hooks()
+        out = raw(x=inputs, y=outputs, dead_mask=dead_mask)
+
+        ops.mark_fired_(self.did_fire[name], out.latent_indices.reshape(-1))      # trainer.py:422
+        self.maybe_all_reduce(self.did_fire[name], "max")
+
+        denom = cfg.grad_acc_steps * cfg.micro_acc_steps * cfg.wandb_log_frequency
+        self._metrics[f"fvu/{name}"] += out.fvu.detach() / denom
+        if cfg.auxk_alpha > 0:
+            self._metrics[f"auxk/{name}"] += out.auxk_loss.detach() / denom
+        if cfg.sae.multi_topk:
+            self._metrics[f"multi_topk_fvu/{name}"] += out.multi_topk_fvu.detach() / denom
+
+        acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
+        loss = out.fvu + cfg.auxk_alpha * out.auxk_loss + out.multi_topk_fvu / 8    # trainer.py:444-446
+        loss.div(acc_steps).backward()
+        return out, n_tokens
+
+    # ------------------------------------------------------------------ the step tail (trainer.py:510-538)
+    def step_tail(self) -> bool:
+        cfg = self.cfg
+        step, substep = divmod(self.global_step + 1, cfg.grad_acc_steps)
+        did_step = False
+        if substep == 0:
+            self._finish_grad_reduce()
+            if cfg.sae.normalize_decoder and not cfg.sae.transcode and not self._fused_projection:
+                for sae in self.saes.values():
+                    sae.remove_gradient_parallel_to_decoder_directions()
+            for optimizer in self.optimizers:
+                optimizer.step()
+                optimizer.zero_grad()
+            for scheduler in self.lr_schedulers:
+                scheduler.step()
+            k = self.get_current_k()
+            for sae in self.saes.values():
+                sae.cfg.k = k
+            for name, counts in self.num_tokens_since_fired.items():
+                ops.dead_counter_step_(counts, self.did_fire[name], self.num_tokens_in_step)
+            self.num_tokens_in_step = 0
+            did_step = True
+            if (step + 1) % cfg.save_every == 0:
+                self.save()
+            if (step + 1) % cfg.wandb_log_frequency == 0:
+                self._flush_metrics(step)
+        self.global_step += 1
+        return did_step
+
+    def _flush_metrics(self, step: int):
+        if not self._metrics:
+            return
+        keys = sorted(self._metrics)
+        vec = torch.stack([self._metrics[k] for k in keys])
+        self.maybe_all_reduce(vec, "mean")
+        vals = vec.tolist()                     # the only host sync of the logging path
+        info = dict(zip(keys, vals))
+        for name in self.saes:
+            dead = self.num_tokens_since_fired[name] > self.cfg.dead_feature_threshold
+            info[f"dead_pct/{name}"] = dead.float().mean().item()
+        info["k"] = self.get_current_k()
+        info["step"] = step
+        self.last_logged = info
+        self._metrics.clear()
+
+    def train_micro_batch(self, batch: dict, mask: Tensor | None = None):
+        """One iteration of the reference's outer loop (trainer.py:453-589) for a batch of
+        ready-made activations."""
+        n_step = 0
+        plan = self.local_hookpoints() if not self.cfg.distribute_modules else self.cfg.hookpoints
+        for hook in plan:
+            item = batch[hook]
+            inputs, outputs = item if isinstance(item, tuple) else (None, item)
+            for name in [n for n in self._names_for(hook)] or [hook]:
+                res = self.train_on_activations(name, inputs, outputs, mask)
+                if res is not None:
+                    n_step = max(n_step, res[1])
+        if self.cfg.distribute_modules and n_step == 0:
+            first = batch[self.cfg.hookpoints[0]]
+            first = first[1] if isinstance(first, tuple) else first
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            n_step = first.reshape(-1, first.shape[-1]).shape[0] * world
+        self.num_tokens_in_step += n_step
+        return self.step_tail()
+
+    def _names_for(self, hook: str):
+        if hook in self.saes:
+            return [hook]
+        return [n for n in self.saes if n.partition("/")[0] == hook]
+
+    def fit(self):
+        k = self.get_current_k()
+        for sae in self.saes.values():
+            sae.cfg.k = k
+        for i, batch in enumerate(self.source):
+            if i < self.global_step:
+                continue                       # resume: skip what was already consumed
+            self.train_micro_batch(batch)
+        self.save()
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:186-227, 648-724)
+    def _checkpoint(self, saes: dict[str, SparseCoder], path: str, rank_zero: bool):
+        for optimizer in self.optimizers:
+            if isinstance(optimizer, ScheduleFreeWrapper):
+                optimizer.eval()
+        for name, sae in saes.items():
+            sae.save_to_disk(f"{path}/{name}")
+        if rank_zero:
+            for i, scheduler in enumerate(self.lr_schedulers):
+                torch.save(scheduler.state_dict(), f"{path}/lr_scheduler_{i}.pt")
+            for i, optimizer in enumerate(self.optimizers):
+                torch.save(optimizer.state_dict(), f"{path}/optimizer_{i}.pt")
+            torch.save({"global_step": self.global_step}, f"{path}/state.pt")
+            self.cfg.save_json(f"{path}/config.json")
+        for optimizer in self.optimizers:
+            if isinstance(optimizer, ScheduleFreeWrapper):
+                optimizer.train()
+        rank = 0 if rank_zero else dist.get_rank()
+        torch.save({"num_tokens_since_fired": self.num_tokens_since_fired, "best_loss": self.best_loss},
+                   f"{path}/rank_{rank}_state.pt")
+
+    def save(self):
+        path = f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}'
+        rank_zero = not dist.is_initialized() or dist.get_rank() == 0
+        if self.cfg.save_dir and (rank_zero or self.cfg.distribute_modules):
+            Path(path).mkdir(parents=True, exist_ok=True)
+            self._checkpoint(self.saes, path, rank_zero)
+        if dist.is_initialized():
+            dist.barrier()
+
+    def load_state(self, path: str):
+        from glob import glob
+
+        from safetensors.torch import load_model
+
+        device = self.device
+        train_state = torch.load(f"{path}/state.pt", map_location=device, weights_only=True)
+        self.global_step = train_state["global_step"]
+        for file in glob(f"{path}/rank_*_state.pt"):
+            rank_state = torch.load(file, map_location=device, weights_only=True)
+            for k in self.saes:
+                if k in rank_state["num_tokens_since_fired"]:
+                    self.num_tokens_since_fired[k] = rank_state["num_tokens_since_fired"][k]
+                if isinstance(rank_state["best_loss"], dict) and k in rank_state["best_loss"]:
+                    self.best_loss[k] = rank_state["best_loss"][k]
+        for i, scheduler in enumerate(self.lr_schedulers):
+            scheduler.load_state_dict(torch.load(f"{path}/lr_scheduler_{i}.pt", map_location=device, weights_only=True))
+        for i, optimizer in enumerate(self.optimizers):
+            optimizer.load_state_dict(torch.load(f"{path}/optimizer_{i}.pt", map_location=device, weights_only=True))
+        for name, sae in self.saes.items():
+            load_model(sae, f"{path}/{name}/sae.safetensors", device=str(device))
+            for p in sae.parameters():
+                torch.autograd.graph.increment_version(p)
+
+
+def _linear_warmup_decay(optimizer, warmup: int, total: int):
+    """transformers.get_linear_schedule_with_warmup (trainer.py:118-122, 140-145)."""
+
+    def f(step: int) -> float:
+        if step < warmup:
+            return step / max(1, warmup)
+        return max(0.0, (total - step) / max(1, total - warmup))
+
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
+
+
+# Support old name for compatibility
+SaeTrainer = Trainer
