@@ -17,6 +17,7 @@
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a contiguous range
 // of 8-latent-tile x 8-token-tile patches.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sphip {
 
@@ -202,6 +203,9 @@ static int launch_gemm(const void* x, const void* W, const void* bias, void* pre
     return SPHIP_OK;
 }
 
+bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, int64_t N, int64_t D,
+                         int64_t M, int relu, hipStream_t s, int* status);   // encoder_gemm256.hip
+
 }  // namespace sphip
 
 extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, int dtype,
@@ -219,6 +223,14 @@ extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* b
     SPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)pre & 15) == 0,
                   SPHIP_EINVAL, "encoder_preacts: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SPHIP_BF16) return launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
+    if (dtype == SPHIP_BF16) {
+        // large shapes: 256x256 LDS-DMA kernel (needs >= one workgroup per CU to pay off);
+        // SPHIP_GEMM=128|256 forces a kernel (tests).
+        const char* force = getenv("SPHIP_GEMM");
+        const bool want256 = force ? (force[0] == '2') : (cdiv(M, 256) * cdiv(N, 256) >= 256);
+        int status = SPHIP_OK;
+        if (want256 && launch_gemm256_bf16(x, W, bias, pre, N, D, M, relu, s, &status)) return status;
+        return launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
+    }
     return launch_gemm<float>(x, W, bias, pre, N, D, M, relu, s);
 }

@@ -51,6 +51,35 @@ def test_encoder_preacts(device, N, D, M, dtype):
         torch.testing.assert_close(got.double(), exact, rtol=1e-5, atol=2e-6 * D**0.5)
 
 
+@pytest.mark.parametrize("N,D,M", [(256, 64, 256), (300, 128, 520), (1000, 192, 700), (512, 4096, 1024),
+                                    (4096, 1024, 4096), (257, 256, 255)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_encoder_preacts_256_tile_kernel(device, monkeypatch, N, D, M, relu):
+    """The large-shape LDS-DMA kernel (forced with SPHIP_GEMM=256) against the exact product and
+    against the 128x128 kernel: both accumulate in fp32 and round once, so they may differ
+    by one bf16 ulp on a few outputs only."""
+    from sparsify_amd import ops
+    torch.manual_seed(N + D + M)
+    xb = torch.randn(N, D).bfloat16()
+    Wb = (torch.randn(M, D) / D**0.5).bfloat16()
+    bb = (torch.randn(M) * 0.1).bfloat16()
+    monkeypatch.setenv("SPHIP_GEMM", "256")
+    got = ops.encoder_preacts(dev(xb), dev(Wb), dev(bb), relu=relu).cpu()
+    monkeypatch.setenv("SPHIP_GEMM", "128")
+    base = ops.encoder_preacts(dev(xb), dev(Wb), dev(bb), relu=relu).cpu()
+    exact = xb.double() @ Wb.double().T + bb.double()
+    if relu:
+        exact = exact.clamp_min(0)
+    torch.testing.assert_close(got.double(), exact, rtol=2**-7, atol=1e-3)
+    assert (got != base).float().mean() < 0.01
+    # integer-valued operands: every product and partial sum is exact -> must be bit-identical
+    xi = torch.randint(-3, 4, (N, D)).bfloat16()
+    Wi = torch.randint(-3, 4, (M, D)).bfloat16()
+    monkeypatch.setenv("SPHIP_GEMM", "256")
+    goti = ops.encoder_preacts(dev(xi), dev(Wi), None, relu=False).cpu()
+    assert torch.equal(goti.float(), (xi.float() @ Wi.float().T).bfloat16().float())
+
+
 # ------------------------------------------------------------------ top-k
 def check_topk(pre_cpu, k, vals, idx, keep=None):
     """Set semantics of torch.topk: selected values are the k largest, indices are valid,
