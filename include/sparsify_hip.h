@@ -96,17 +96,22 @@ int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_
  *   gW[j,:]      = sum_{e in seg j} coeff[e] * rows[e / k, :]          (all M rows written)
  *   gbias[j]     = sum_{e in seg j} coeff[e]                           (if gbias != NULL)
  *   dcoeff[e]    = < rows[e / k, :], W[j,:] >                          (if dcoeff != NULL)
+ * row_shift (D) fp32 or NULL: when given, the rows are taken as rows[n,:] - row_shift[:]
+ *   for gW only (the encoder input x - b_dec, sparse_coder.py:192, without materialising
+ *   it: gW[j,:] = sum c*rows - (sum c)*row_shift).
  * coeff (N,k) of coeff_dtype, rows (N,D) of rows_dtype, W (M,D) fp32, outputs fp32.
  * Sums run in segment order, so results are bitwise reproducible. */
 int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                 int coeff_dtype, const void* rows, int rows_dtype, const float* W,
-                                float* gW, float* gbias, float* dcoeff, int64_t N, int64_t k,
-                                int64_t M, int64_t D, void* stream);
+                                float* gW, float* gbias, float* dcoeff, const float* row_shift,
+                                int64_t N, int64_t k, int64_t M, int64_t D, void* stream);
 
 /* ---------------------------------------------------------------- loss (FVU / AuxK) */
 
 /* sparse_coder.py:228: tv = sum((y - mean_0(y))^2). y (N,D) of y_dtype; out tv[0] fp32.
- * workspace: sphip_reduce_workspace_bytes(N, D). Two-pass, fp32, fixed summation order. */
+ * workspace: sphip_reduce_workspace_bytes(N, D). Two-pass, fixed summation order. For bf16 y
+ * the mean and y - mean are rounded to bf16 as the reference's autocast does; squares and
+ * sums are fp32. */
 size_t sphip_reduce_workspace_bytes(int64_t N, int64_t D);
 int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64_t D, float* tv,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -104,8 +104,11 @@ def scatter_scalar(idx: Tensor, coeff: Tensor, M: int) -> Tensor:
 
 # --------------------------------------------------------------------------- loss pieces
 def total_variance(y: Tensor) -> Tensor:
-    """sum((y - mean_0(y))^2) over batch and features -- sparse_coder.py:228."""
-    return (y - y.mean(0)).pow(2).sum()
+    """sum((y - mean_0(y))^2) over batch and features -- sparse_coder.py:228.
+
+    For bf16 activations the reference runs under CUDA autocast: mean and the subtraction
+    stay in bf16, pow and sum are on autocast's fp32 list."""
+    return (y - y.mean(0)).float().pow(2).sum()
 
 
 def auxk_select(pre: Tensor, dead_mask: Tensor, d_in: int):

@@ -91,16 +91,25 @@ __global__ __launch_bounds__(256) void tv_partial_kernel(const T* __restrict__ y
     const int64_t r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
     float acc = 0.f;
     if (col < D) {
+        // bf16 activations: the reference computes y.mean(0) and y - mean in bf16 and only the
+        // square and the sum in fp32 (autocast fp32 policy for pow / sum,
+        // sparse_coder.py:205-209,228); reproduce those two roundings.
+        constexpr bool LOW = sizeof(T) == 2;
         float m[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) m[v] = mean[col + v];
+        for (int v = 0; v < VEC; ++v) m[v] = LOW ? bf16_to_f32(f32_to_bf16(mean[col + v])) : mean[col + v];
         for (int64_t r = r0; r < r1; ++r) {
             if (VEC == 4) {
                 const float4 x = load4(y + r * D + col);
-                const float d0 = x.x - m[0], d1 = x.y - m[1 % VEC], d2 = x.z - m[2 % VEC], d3 = x.w - m[3 % VEC];
+                float d0 = x.x - m[0], d1 = x.y - m[1 % VEC], d2 = x.z - m[2 % VEC], d3 = x.w - m[3 % VEC];
+                if (LOW) {
+                    d0 = bf16_to_f32(f32_to_bf16(d0)); d1 = bf16_to_f32(f32_to_bf16(d1));
+                    d2 = bf16_to_f32(f32_to_bf16(d2)); d3 = bf16_to_f32(f32_to_bf16(d3));
+                }
                 acc = fmaf(d0, d0, acc); acc = fmaf(d1, d1, acc); acc = fmaf(d2, d2, acc); acc = fmaf(d3, d3, acc);
             } else {
-                const float d = Elem<T>::load(y, r * D + col) - m[0];
+                float d = Elem<T>::load(y, r * D + col) - m[0];
+                if (LOW) d = bf16_to_f32(f32_to_bf16(d));
                 acc = fmaf(d, d, acc);
             }
         }

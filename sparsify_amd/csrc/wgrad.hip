@@ -14,6 +14,7 @@
 // The dot product for dcoeff is a 6-step wave reduction, no LDS, no barriers. Every output
 // row is written exactly once (zeros for empty segments), sums run in segment order.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sphip {
 
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void seg_wgrad_kernel(const unsigned* __restri
                                                         const RT* __restrict__ rows,
                                                         const float* __restrict__ W, float* __restrict__ gW,
                                                         float* __restrict__ gbias, float* __restrict__ dcoeff,
-                                                        int k, int M, int D) {
+                                                        const float* __restrict__ row_shift, int k, int M,
+                                                        int D) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
@@ -76,39 +78,162 @@ __global__ __launch_bounds__(256) void seg_wgrad_kernel(const unsigned* __restri
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int col = c0 + (lane + 64 * v) * 4;
-            if (live[v]) *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc[v];
+            if (!live[v]) continue;
+            if (row_shift != nullptr) {
+                // rows were given un-shifted: sum c*(row - shift) = sum c*row - (sum c)*shift
+                const float4 sh = *reinterpret_cast<const float4*>(row_shift + col);
+                acc[v].x = fmaf(-bsum, sh.x, acc[v].x);
+                acc[v].y = fmaf(-bsum, sh.y, acc[v].y);
+                acc[v].z = fmaf(-bsum, sh.z, acc[v].z);
+                acc[v].w = fmaf(-bsum, sh.w, acc[v].w);
+            }
+            *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc[v];
         }
         if (gbias != nullptr && c0 == 0 && lane == 0) gbias[j] = bsum;
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Column-sliced variant (no dcoeff): the gradient is computed one 128-byte column slice of
+// `rows` at a time. A slice of the whole token batch (N x 128 B, 2 MiB at N = 16384) fits
+// one XCD's 4 MiB L2, and all workgroups that land on one XCD (blockIdx % 8) work through
+// the same slice before moving on, so the k-fold re-reads of every row piece are L2 hits
+// instead of Infinity-Cache / HBM traffic. Eight lanes cover one 128-B row piece; each
+// 8-lane group owns one latent, so a wave reduces 8 latents at once, sequentially in
+// segment order (bitwise the same sums as the full-row kernel), with 4 entries per group in
+// flight. Outputs are written with non-temporal stores to keep the slice resident.
+template <typename T> struct Piece;
+template <> struct Piece<float> {
+    static constexpr int COLS = 4;    // columns per lane (16 B)
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+template <> struct Piece<bf16_t> {
+    static constexpr int COLS = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+        v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    }
+};
+
+template <typename RT, typename CT>
+__global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const unsigned* __restrict__ perm,
+                                                               const int* __restrict__ seg_begin,
+                                                               const CT* __restrict__ coeff,
+                                                               const RT* __restrict__ rows, float* __restrict__ gW,
+                                                               float* __restrict__ gbias,
+                                                               const float* __restrict__ row_shift, int k, int M,
+                                                               int D, int blocks_per_slice, int num_slices) {
+    constexpr int C = Piece<RT>::COLS;
+    constexpr int SLICE_COLS = 8 * C;
+    // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
+    const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const unsigned slice = xcd + 8 * (local / (unsigned)blocks_per_slice);
+    if (slice >= (unsigned)num_slices) return;
+    const unsigned lblock = local % (unsigned)blocks_per_slice;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+    const int j = (int)lblock * 32 + (threadIdx.x >> 6) * 8 + grp;
+    const int col = (int)slice * SLICE_COLS + sub * C;
+    const bool live = (j < M) && (col < D);
+
+    int beg = 0, end = 0;
+    if (j < M) { beg = seg_begin[j]; end = seg_begin[j + 1]; }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    float bsum = 0.f;
+    const RT* base = rows + col;
+
+    constexpr int U = 4;
+    for (int p = beg; p < end; p += U) {
+        unsigned e[U];
+        float cf[U];
+        float v[U][C];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = (p + u < end) ? perm[p + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool on = p + u < end;
+            cf[u] = on ? Elem<CT>::load(coeff, e[u]) : 0.f;
+            if (on && live) Piece<RT>::load(base + (int64_t)(e[u] / (unsigned)k) * D, v[u]);
+            else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[u][c] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < end) {     // keeps the exact sequential fma chain of the full-row kernel
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(cf[u], v[u][c], acc[c]);
+                bsum += cf[u];
+            }
+        }
+    }
+    if (live) {
+        if (row_shift != nullptr) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(-bsum, row_shift[col + c], acc[c]);
+        }
+        float* o = gW + (int64_t)j * D + col;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 t = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+            __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o + c));
+        }
+    }
+    if (gbias != nullptr && slice == 0 && sub == 0 && j < M) gbias[j] = bsum;
+}
+
+template <typename RT, typename CT>
+static bool launch_sliced(const unsigned* perm, const int* seg, const void* coeff, const void* rows, float* gW,
+                          float* gbias, const float* row_shift, int k, int M, int D, hipStream_t s) {
+    constexpr int C = Piece<RT>::COLS;
+    if (D % C != 0) return false;
+    const int num_slices = (int)cdiv(D, 8 * C);
+    const int bps = (int)cdiv(M, 32);
+    const int64_t rounds = cdiv(num_slices, 8);
+    const int64_t nblocks = rounds * bps * 8;
+    if (nblocks >= (1ll << 31)) return false;
+    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, CT>), dim3((unsigned)nblocks), dim3(256), 0, s, perm, seg,
+                       (const CT*)coeff, (const RT*)rows, gW, gbias, row_shift, k, M, D, bps, num_slices);
+    return true;
+}
+
 template <typename RT, typename CT, bool DOT>
 static void launch_nv(const unsigned* perm, const int* seg, const void* coeff, const void* rows, const float* W,
-                      float* gW, float* gbias, float* dcoeff, int k, int M, int D, hipStream_t s) {
+                      float* gW, float* gbias, float* dcoeff, const float* row_shift, int k, int M, int D, hipStream_t s) {
     dim3 grid((unsigned)cdiv(M, 4)), block(256);
     if (D <= 256)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 1, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 1, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
     else if (D <= 1024)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 4, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 4, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
     else if (D <= 2048)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 8, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 8, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
     else
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 16, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 16, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
 }
 
 template <typename RT, typename CT>
 static void launch_dot(bool dot, const unsigned* perm, const int* seg, const void* coeff, const void* rows,
-                       const float* W, float* gW, float* gbias, float* dcoeff, int k, int M, int D, hipStream_t s) {
-    if (dot) launch_nv<RT, CT, true>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, k, M, D, s);
-    else launch_nv<RT, CT, false>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, k, M, D, s);
+                       const float* W, float* gW, float* gbias, float* dcoeff, const float* row_shift, int k, int M, int D, hipStream_t s) {
+    if (dot) launch_nv<RT, CT, true>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, row_shift, k, M, D, s);
+    else launch_nv<RT, CT, false>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, row_shift, k, M, D, s);
 }
 
 }  // namespace sphip
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
-                                           float* gW, float* gbias, float* dcoeff, int64_t N, int64_t k, int64_t M,
-                                           int64_t D, void* stream) {
+                                           float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
+                                           int64_t k, int64_t M, int64_t D, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && gW, SPHIP_EINVAL, "segmented_weight_grad: null pointer");
@@ -117,18 +242,33 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     SPHIP_REQUIRE(N * k < (1ll << 31) && M < (1ll << 31) - 4 && D < (1ll << 30), SPHIP_EUNSUPPORTED,
                   "segmented_weight_grad: shape too large");
     SPHIP_REQUIRE(D % 4 == 0, SPHIP_EUNSUPPORTED, "segmented_weight_grad: D=%lld must be a multiple of 4", (long long)D);
-    SPHIP_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)gW & 15) == 0 && ((uintptr_t)W & 15) == 0, SPHIP_EINVAL,
-                  "segmented_weight_grad: rows/W/gW must be 16-byte aligned");
+    SPHIP_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)gW & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+                      ((uintptr_t)row_shift & 15) == 0,
+                  SPHIP_EINVAL, "segmented_weight_grad: rows/W/gW/row_shift must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const bool dot = dcoeff != nullptr;
     const unsigned* pp = perm;
     const int* sp = seg_begin;
+    const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" (tests)
+    if (!dot && !(force && force[0] == 'f')) {
+        bool done;
+        if (rows_dtype == SPHIP_F32)
+            done = coeff_dtype == SPHIP_F32 ? launch_sliced<float, float>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
+                                            : launch_sliced<float, bf16_t>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
+        else
+            done = coeff_dtype == SPHIP_F32 ? launch_sliced<bf16_t, float>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
+                                            : launch_sliced<bf16_t, bf16_t>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
+        if (done) {
+            SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
+            return SPHIP_OK;
+        }
+    }
     if (rows_dtype == SPHIP_F32) {
-        if (coeff_dtype == SPHIP_F32) launch_dot<float, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, (int)k, (int)M, (int)D, s);
-        else launch_dot<float, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, (int)k, (int)M, (int)D, s);
+        if (coeff_dtype == SPHIP_F32) launch_dot<float, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        else launch_dot<float, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
     } else {
-        if (coeff_dtype == SPHIP_F32) launch_dot<bf16_t, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, (int)k, (int)M, (int)D, s);
-        else launch_dot<bf16_t, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, (int)k, (int)M, (int)D, s);
+        if (coeff_dtype == SPHIP_F32) launch_dot<bf16_t, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        else launch_dot<bf16_t, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
     }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad");
     return SPHIP_OK;

@@ -79,7 +79,13 @@ class FusedEncoder(torch.autograd.Function):
         x2 = input.reshape(-1, input.shape[-1]).contiguous()
         low = _autocast_bf16() or (weight.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16)
 
-        if b_dec is not None:
+        shift = None
+        if b_dec is not None and low and x2.dtype == torch.bfloat16:
+            # bf16 activations: the fp32 (x - b_dec) is never materialised; the backward reads
+            # the bf16 rows (half the gather bytes) and applies the shift analytically
+            x_low = ops.center_cast(x2, b_dec.detach().contiguous(), want_f32=False, want_bf16=True)[1]
+            rows, shift = x2, b_dec.detach().clone()
+        elif b_dec is not None:
             rows, x_low = ops.center_cast(x2, b_dec.detach().contiguous(), want_f32=True, want_bf16=low)
         else:
             rows = x2
@@ -99,7 +105,7 @@ class FusedEncoder(torch.autograd.Function):
             values, indices = ops.groupmax(pre, k)
         ops.forget_segments(indices)
 
-        ctx.save_for_backward(rows, weight, bias, indices, b_dec)
+        ctx.save_for_backward(rows, weight, bias, indices, b_dec, shift)
         ctx.k = k
         ctx.lead = lead
         ctx.in_shape = input.shape
@@ -108,7 +114,7 @@ class FusedEncoder(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_values, grad_indices, grad_preacts):
-        rows, weight, bias, indices, b_dec = ctx.saved_tensors
+        rows, weight, bias, indices, b_dec, shift = ctx.saved_tensors
         grad_input = grad_weight = grad_bias = grad_bdec = None
         M = weight.shape[0]
         gv = grad_values.reshape(-1, ctx.k).contiguous()
@@ -119,7 +125,7 @@ class FusedEncoder(torch.autograd.Function):
 
         if need_w or need_b or need_bdec:
             seg = ops.cached_segments(indices, M)
-            grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True)
+            grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True, row_shift=shift)
             if bias is None:
                 gb_full, grad_bias = grad_bias, None
             else:

@@ -232,7 +232,7 @@ def cached_segments(idx: Tensor, M: int) -> LatentSegments:
 
 
 def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: Tensor | None = None,
-                          want_bias: bool = False, want_dcoeff: bool = False):
+                          want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None):
     """(gW, gbias, dcoeff); xformers.py:88-136 and fused_encoder.py:67-84."""
     _req(coeff, "coeff", ndim=2)
     _req(rows, "rows", ndim=2)
@@ -246,13 +246,17 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
             raise ValueError("segmented_weight_grad: W shape mismatch")
     if want_dcoeff and W is None:
         raise ValueError("dcoeff needs W")
+    if row_shift is not None:
+        _req(row_shift, "row_shift", torch.float32, 1)
+        if row_shift.shape[0] != D:
+            raise ValueError("segmented_weight_grad: row_shift shape mismatch")
     gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
     gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
     dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
     _ev = timer.start("sphip_segmented_weight_grad", rows)
     check(_lib.load().sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
                                                  _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
-                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), N, k, M, D, _stream(rows)),
+                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), _ptr(row_shift), N, k, M, D, _stream(rows)),
           "sphip_segmented_weight_grad")
     timer.stop(_ev, rows)
     return gW, gb, dc
