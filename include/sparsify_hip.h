@@ -100,11 +100,14 @@ int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_
  *   for gW only (the encoder input x - b_dec, sparse_coder.py:192, without materialising
  *   it: gW[j,:] = sum c*rows - (sum c)*row_shift).
  * coeff (N,k) of coeff_dtype, rows (N,D) of rows_dtype, W (M,D) fp32, outputs fp32.
- * Sums run in segment order, so results are bitwise reproducible. */
+ * Sums run in segment order, so results are bitwise reproducible.
+ * workspace (sphip_weight_grad_workspace_bytes): the segment-ordered (entry, coeff) list. */
+size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k);
 int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                 int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                                 float* gW, float* gbias, float* dcoeff, const float* row_shift,
-                                int64_t N, int64_t k, int64_t M, int64_t D, void* stream);
+                                int64_t N, int64_t k, int64_t M, int64_t D, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- loss (FVU / AuxK) */
 

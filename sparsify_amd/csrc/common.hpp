@@ -33,7 +33,27 @@ static inline bool valid_dtype(int dt) { return dt == SPHIP_F32 || dt == SPHIP_B
 static inline size_t dtype_size(int dt) { return dt == SPHIP_BF16 ? 2 : 4; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Division of a 32-bit unsigned by a launch-invariant divisor (Granlund-Montgomery):
+// q = (t + ((n - t) >> sh1)) >> sh2 with t = umulhi(n, magic).
+struct FastDiv {
+    unsigned magic, sh1, sh2;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.magic = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
 // ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv f) {
+    const unsigned t = __umulhi(n, f.magic);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 typedef unsigned short bf16_t;   // raw bf16 storage
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }

@@ -18,14 +18,27 @@
 
 namespace sphip {
 
-template <typename RT, typename CT, int NV, bool DOT>
-__global__ __launch_bounds__(256) void seg_wgrad_kernel(const unsigned* __restrict__ perm,
+// Segment-ordered entry list: packed[p] = {entry id e = perm[p], fp32 bits of coeff[e]}.
+// Turns the per-entry dependent gather (perm -> coeff) of the reduction kernels into one
+// sequential 8-byte stream; built once per call (N*k entries, a few tens of microseconds).
+template <typename CT>
+__global__ __launch_bounds__(256) void seg_pack_kernel(const unsigned* __restrict__ perm,
+                                                       const CT* __restrict__ coeff, int64_t E,
+                                                       uint2* __restrict__ packed) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < E) {
+        const unsigned e = perm[p];
+        packed[p] = make_uint2(e, __float_as_uint(Elem<CT>::load(coeff, e)));
+    }
+}
+
+template <typename RT, int NV, bool DOT>
+__global__ __launch_bounds__(256) void seg_wgrad_kernel(const uint2* __restrict__ packed,
                                                         const int* __restrict__ seg_begin,
-                                                        const CT* __restrict__ coeff,
                                                         const RT* __restrict__ rows,
                                                         const float* __restrict__ W, float* __restrict__ gW,
                                                         float* __restrict__ gbias, float* __restrict__ dcoeff,
-                                                        const float* __restrict__ row_shift, int k, int M,
+                                                        const float* __restrict__ row_shift, FastDiv kdiv, int M,
                                                         int D) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,9 +59,10 @@ __global__ __launch_bounds__(256) void seg_wgrad_kernel(const unsigned* __restri
         }
         float bsum = 0.f;
         for (int p = beg; p < end; ++p) {
-            const unsigned e = perm[p];
-            const float c = Elem<CT>::load(coeff, e);
-            const RT* rp = rows + (int64_t)(e / (unsigned)k) * D + c0 + lane * 4;
+            const uint2 pk = packed[p];
+            const unsigned e = pk.x;
+            const float c = __uint_as_float(pk.y);
+            const RT* rp = rows + (int64_t)fastdiv(e, kdiv) * D + c0 + lane * 4;
             float4 r[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) r[v] = live[v] ? load4(rp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -121,14 +135,14 @@ template <> struct Piece<bf16_t> {
     }
 };
 
-template <typename RT, typename CT>
-__global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const unsigned* __restrict__ perm,
+template <typename RT>
+__global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
-                                                               const CT* __restrict__ coeff,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
-                                                               const float* __restrict__ row_shift, int k, int M,
-                                                               int D, int blocks_per_slice, int num_slices) {
+                                                               const float* __restrict__ row_shift, FastDiv kdiv,
+                                                               int M, int D, int blocks_per_slice,
+                                                               int num_slices) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
@@ -152,16 +166,13 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const unsigned* _
 
     constexpr int U = 4;
     for (int p = beg; p < end; p += U) {
-        unsigned e[U];
-        float cf[U];
+        uint2 pk[U];
         float v[U][C];
 #pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = (p + u < end) ? perm[p + u] : 0u;
+        for (int u = 0; u < U; ++u) pk[u] = (p + u < end) ? packed[p + u] : make_uint2(0u, 0u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool on = p + u < end;
-            cf[u] = on ? Elem<CT>::load(coeff, e[u]) : 0.f;
-            if (on && live) Piece<RT>::load(base + (int64_t)(e[u] / (unsigned)k) * D, v[u]);
+            if ((p + u < end) && live) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * D, v[u]);
             else {
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[u][c] = 0.f;
@@ -170,9 +181,10 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const unsigned* _
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (p + u < end) {     // keeps the exact sequential fma chain of the full-row kernel
+                const float cf = __uint_as_float(pk[u].y);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = fmaf(cf[u], v[u][c], acc[c]);
-                bsum += cf[u];
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
+                bsum += cf;
             }
         }
     }
@@ -192,9 +204,9 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const unsigned* _
     if (gbias != nullptr && slice == 0 && sub == 0 && j < M) gbias[j] = bsum;
 }
 
-template <typename RT, typename CT>
-static bool launch_sliced(const unsigned* perm, const int* seg, const void* coeff, const void* rows, float* gW,
-                          float* gbias, const float* row_shift, int k, int M, int D, hipStream_t s) {
+template <typename RT>
+static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, float* gW, float* gbias,
+                          const float* row_shift, int k, int M, int D, hipStream_t s) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -202,38 +214,38 @@ static bool launch_sliced(const unsigned* perm, const int* seg, const void* coef
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, CT>), dim3((unsigned)nblocks), dim3(256), 0, s, perm, seg,
-                       (const CT*)coeff, (const RT*)rows, gW, gbias, row_shift, k, M, D, bps, num_slices);
+    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
+                       (const RT*)rows, gW, gbias, row_shift, make_fastdiv((unsigned)k), M, D, bps, num_slices);
     return true;
 }
 
-template <typename RT, typename CT, bool DOT>
-static void launch_nv(const unsigned* perm, const int* seg, const void* coeff, const void* rows, const float* W,
-                      float* gW, float* gbias, float* dcoeff, const float* row_shift, int k, int M, int D, hipStream_t s) {
+template <typename RT, bool DOT>
+static void launch_nv(const uint2* packed, const int* seg, const void* rows, const float* W, float* gW, float* gbias,
+                      float* dcoeff, const float* row_shift, int k, int M, int D, hipStream_t s) {
     dim3 grid((unsigned)cdiv(M, 4)), block(256);
+    const FastDiv kd = make_fastdiv((unsigned)k);
     if (D <= 256)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 1, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, 1, DOT>), grid, block, 0, s, packed, seg, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, kd, M, D);
     else if (D <= 1024)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 4, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, 4, DOT>), grid, block, 0, s, packed, seg, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, kd, M, D);
     else if (D <= 2048)
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 8, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, 8, DOT>), grid, block, 0, s, packed, seg, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, kd, M, D);
     else
-        hipLaunchKernelGGL((seg_wgrad_kernel<RT, CT, 16, DOT>), grid, block, 0, s, perm, seg, (const CT*)coeff, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, k, M, D);
-}
-
-template <typename RT, typename CT>
-static void launch_dot(bool dot, const unsigned* perm, const int* seg, const void* coeff, const void* rows,
-                       const float* W, float* gW, float* gbias, float* dcoeff, const float* row_shift, int k, int M, int D, hipStream_t s) {
-    if (dot) launch_nv<RT, CT, true>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, row_shift, k, M, D, s);
-    else launch_nv<RT, CT, false>(perm, seg, coeff, rows, W, gW, gbias, dcoeff, row_shift, k, M, D, s);
+        hipLaunchKernelGGL((seg_wgrad_kernel<RT, 16, DOT>), grid, block, 0, s, packed, seg, (const RT*)rows, W, gW, gbias, dcoeff, row_shift, kd, M, D);
 }
 
 }  // namespace sphip
 
+extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k) {
+    if (N <= 0 || k <= 0) return 0;
+    return (size_t)N * (size_t)k * sizeof(uint2);
+}
+
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                                            float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
-                                           int64_t k, int64_t M, int64_t D, void* stream) {
+                                           int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && gW, SPHIP_EINVAL, "segmented_weight_grad: null pointer");
@@ -245,30 +257,34 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     SPHIP_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)gW & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
                       ((uintptr_t)row_shift & 15) == 0,
                   SPHIP_EINVAL, "segmented_weight_grad: rows/W/gW/row_shift must be 16-byte aligned");
+    const size_t need = sphip_weight_grad_workspace_bytes(N, k);
+    SPHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need, SPHIP_EWORKSPACE,
+                  "segmented_weight_grad: workspace %zu < %zu bytes", workspace_bytes, need);
+    SPHIP_REQUIRE(((uintptr_t)workspace & 15) == 0, SPHIP_EINVAL, "segmented_weight_grad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const bool dot = dcoeff != nullptr;
-    const unsigned* pp = perm;
-    const int* sp = seg_begin;
+    const int64_t E = N * k;
+    uint2* packed = (uint2*)workspace;
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, packed);
+    else
+        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, packed);
     const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" (tests)
     if (!dot && !(force && force[0] == 'f')) {
-        bool done;
-        if (rows_dtype == SPHIP_F32)
-            done = coeff_dtype == SPHIP_F32 ? launch_sliced<float, float>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
-                                            : launch_sliced<float, bf16_t>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
-        else
-            done = coeff_dtype == SPHIP_F32 ? launch_sliced<bf16_t, float>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
-                                            : launch_sliced<bf16_t, bf16_t>(pp, sp, coeff, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
+        const bool done = rows_dtype == SPHIP_F32
+                              ? launch_sliced<float>(packed, seg_begin, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
+                              : launch_sliced<bf16_t>(packed, seg_begin, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
         if (done) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
         }
     }
     if (rows_dtype == SPHIP_F32) {
-        if (coeff_dtype == SPHIP_F32) launch_dot<float, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
-        else launch_dot<float, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        if (dot) launch_nv<float, true>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        else launch_nv<float, false>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
     } else {
-        if (coeff_dtype == SPHIP_F32) launch_dot<bf16_t, float>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
-        else launch_dot<bf16_t, bf16_t>(dot, pp, sp, coeff, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        if (dot) launch_nv<bf16_t, true>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
+        else launch_nv<bf16_t, false>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
     }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad");
     return SPHIP_OK;

@@ -110,12 +110,15 @@ class FusedEncoder(torch.autograd.Function):
         ctx.lead = lead
         ctx.in_shape = input.shape
         ctx.mark_non_differentiable(indices, pre)
+        ctx.set_materialize_grads(False)        # no (N, M) zero tensor for the ignored grad_preacts
         return (values.reshape(*lead, k), indices.reshape(*lead, k), pre.reshape(*lead, pre.shape[-1]))
 
     @staticmethod
     def backward(ctx, grad_values, grad_indices, grad_preacts):
         rows, weight, bias, indices, b_dec, shift = ctx.saved_tensors
         grad_input = grad_weight = grad_bias = grad_bdec = None
+        if grad_values is None:
+            return None, None, None, None, None, None
         M = weight.shape[0]
         gv = grad_values.reshape(-1, ctx.k).contiguous()
         if weight.dtype != torch.float32:

@@ -253,10 +253,13 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
     gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
     gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
     dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
+    lib = _lib.load()
+    ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k), "wgrad")
     _ev = timer.start("sphip_segmented_weight_grad", rows)
-    check(_lib.load().sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
+    check(lib.sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
                                                  _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
-                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), _ptr(row_shift), N, k, M, D, _stream(rows)),
+                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), _ptr(row_shift), N, k, M, D, ws.data_ptr(), ws.numel(),
+                                         _stream(rows)),
           "sphip_segmented_weight_grad")
     timer.stop(_ev, rows)
     return gW, gb, dc

@@ -53,11 +53,14 @@ class ResidualLoss(torch.autograd.Function):
         ctx.pred_shape = pred.shape
         e_out = e.reshape(pred.shape)
         ctx.mark_non_differentiable(e_out)
+        ctx.set_materialize_grads(False)
         return loss.reshape(()), e_out
 
     @staticmethod
     def backward(ctx, g_loss, g_e):
         e, tv = ctx.saved_tensors
+        if g_loss is None:
+            return None, None, None
         g = g_loss.reshape(1).contiguous().float()
         return ops.scale_by_ratio(e, -2.0, g, tv).reshape(ctx.pred_shape), None, None
 

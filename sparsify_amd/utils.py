@@ -20,11 +20,14 @@ class SparseDecode(torch.autograd.Function):
                                        None if bias is None else bias.detach())
         ctx.save_for_backward(indices, weight, per_sample_weights)
         ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, gradient):
         indices, weight, psw = ctx.saved_tensors
+        if gradient is None:
+            return None, None, None, None
         g = gradient.contiguous()
         if g.dtype != torch.float32:
             g = g.float()
