@@ -135,13 +135,34 @@ template <> struct Piece<bf16_t> {
     }
 };
 
+// rows (N, D) -> slice-major copy [slice][n][128 B]. In the row-major layout the pieces of one
+// slice are D*sizeof(RT) bytes apart (8 KiB at D = 4096 bf16): a power-of-two stride that maps
+// the whole slice onto a handful of L2 sets. The slice-major copy makes every slice one
+// contiguous N x 128 B block. One 16-B chunk per thread; columns past D are zero-filled.
+template <typename RT>
+__global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__ rows, uint4* __restrict__ out,
+                                                          int64_t N, int D, int num_slices) {
+    constexpr int C = Piece<RT>::COLS;
+    const int64_t chunks_per_row = (int64_t)num_slices * 8;
+    const int64_t total = N * chunks_per_row;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / chunks_per_row;
+        const int ch = (int)(i % chunks_per_row);          // chunk inside the row: slice*8 + sub
+        const int col = ch * C;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (col < D) v = *reinterpret_cast<const uint4*>(rows + n * D + col);
+        out[((int64_t)(ch >> 3) * N + n) * 8 + (ch & 7)] = v;
+    }
+}
+
 template <typename RT>
 __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
                                                                const float* __restrict__ row_shift, FastDiv kdiv,
-                                                               int M, int D, int blocks_per_slice,
+                                                               int64_t N, int M, int D, int blocks_per_slice,
                                                                int num_slices) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
@@ -162,7 +183,8 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     float bsum = 0.f;
-    const RT* base = rows + col;
+    // `rows` is the slice-major copy: piece of token n = base + n * 128 B
+    const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
     constexpr int U = 4;
     for (int p = beg; p < end; p += U) {
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
         for (int u = 0; u < U; ++u) pk[u] = (p + u < end) ? packed[p + u] : make_uint2(0u, 0u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if ((p + u < end) && live) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * D, v[u]);
+            if ((p + u < end) && live) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
             else {
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[u][c] = 0.f;
@@ -205,17 +227,23 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 }
 
 template <typename RT>
-static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, float* gW, float* gbias,
-                          const float* row_shift, int k, int M, int D, hipStream_t s) {
+static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
+                          float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
+    {
+        int64_t blocks = cdiv(N * num_slices * 8, 256);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL((slice_major_kernel<RT>), dim3((unsigned)blocks), dim3(256), 0, s, (const RT*)rows,
+                           (uint4*)rows_sm, N, D, num_slices);
+    }
     const int bps = (int)cdiv(M, 32);
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
     hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
-                       (const RT*)rows, gW, gbias, row_shift, make_fastdiv((unsigned)k), M, D, bps, num_slices);
+                       (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices);
     return true;
 }
 
@@ -236,9 +264,12 @@ static void launch_nv(const uint2* packed, const int* seg, const void* rows, con
 
 }  // namespace sphip
 
-extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k) {
-    if (N <= 0 || k <= 0) return 0;
-    return (size_t)N * (size_t)k * sizeof(uint2);
+static size_t packed_bytes(int64_t N, int64_t k) { return (((size_t)N * (size_t)k * sizeof(uint2)) + 255) & ~(size_t)255; }
+
+extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
+    if (N <= 0 || k <= 0 || D <= 0) return 0;
+    // packed entry list + slice-major copy of `rows` (<= N * roundup(D*4, 128) bytes)
+    return packed_bytes(N, k) + (size_t)N * (size_t)(((D * 4 + 127) / 128) * 128);
 }
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
@@ -257,14 +288,15 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     SPHIP_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)gW & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
                       ((uintptr_t)row_shift & 15) == 0,
                   SPHIP_EINVAL, "segmented_weight_grad: rows/W/gW/row_shift must be 16-byte aligned");
-    const size_t need = sphip_weight_grad_workspace_bytes(N, k);
+    const size_t need = sphip_weight_grad_workspace_bytes(N, k, D);
     SPHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need, SPHIP_EWORKSPACE,
                   "segmented_weight_grad: workspace %zu < %zu bytes", workspace_bytes, need);
-    SPHIP_REQUIRE(((uintptr_t)workspace & 15) == 0, SPHIP_EINVAL, "segmented_weight_grad: workspace must be 16-byte aligned");
+    SPHIP_REQUIRE(((uintptr_t)workspace & 255) == 0, SPHIP_EINVAL, "segmented_weight_grad: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const bool dot = dcoeff != nullptr;
     const int64_t E = N * k;
     uint2* packed = (uint2*)workspace;
+    void* rows_sm = (char*)workspace + packed_bytes(N, k);
     if (coeff_dtype == SPHIP_F32)
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, packed);
     else
@@ -272,8 +304,8 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" (tests)
     if (!dot && !(force && force[0] == 'f')) {
         const bool done = rows_dtype == SPHIP_F32
-                              ? launch_sliced<float>(packed, seg_begin, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s)
-                              : launch_sliced<bf16_t>(packed, seg_begin, rows, gW, gbias, row_shift, (int)k, (int)M, (int)D, s);
+                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s)
+                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s);
         if (done) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;

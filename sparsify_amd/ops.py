@@ -254,7 +254,7 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
     gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
     dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
     lib = _lib.load()
-    ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k), "wgrad")
+    ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
     _ev = timer.start("sphip_segmented_weight_grad", rows)
     check(lib.sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
                                                  _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
