@@ -75,7 +75,8 @@ int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, 
  * grad-input gather of FusedEncoder.backward, fused_encoder.py:58-64:
  *   out[n,:] = sum_s coeff[n,s] * table[idx[n,s],:]  (+ bias[:] if bias != NULL)
  * idx (N,k) int64 in [0,M); coeff (N,k) of coeff_dtype; table (M,D) fp32; out (N,D) fp32.
- * fp32 accumulation in slot order s = 0..k-1 (deterministic). */
+ * fp32 accumulation in slot order s = 0..k-1 (deterministic). A negative index marks an
+ * inactive slot (latent-sharded decode: the latent lives on another GPU); it is skipped. */
 int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff, int coeff_dtype,
                                const float* table, const float* bias, float* out, int64_t N,
                                int64_t k, int64_t M, int64_t D, void* stream);
@@ -85,6 +86,8 @@ int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff, int coeff_
  *   seg_begin (M+1) int32: entries of latent j are perm[seg_begin[j] : seg_begin[j+1]]
  *   perm (N*k) uint32   : entry ids e = n*k + s, ascending inside a segment (the reference's
  *                         order inside a segment is arrival order of atomics; ours is fixed).
+ * Negative (inactive) ids are placed after all real segments: seg_begin[M] = number of
+ * active entries, and the reduction kernels never visit them (their dcoeff is 0).
  * Requires N*k < 2^31 (as xformers.py:156). workspace: sphip_segments_workspace_bytes. */
 size_t sphip_segments_workspace_bytes(int64_t N, int64_t k, int64_t M);
 int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_t M,

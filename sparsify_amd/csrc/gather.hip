@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
         const float* rp[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            rp[u] = tcol + ip[s + u] * (int64_t)D;
-            w[u] = Elem<CT>::load(cp, s + u);
+            // a negative index marks an inactive slot (latent owned by another shard): weight
+            // 0 and row 0 as a stand-in address (always cache-resident), so the unrolled load
+            // batch stays branch-free
+            const int64_t j = ip[s + u];
+            rp[u] = tcol + (j < 0 ? 0 : j) * (int64_t)D;
+            w[u] = j < 0 ? 0.f : Elem<CT>::load(cp, s + u);
         }
         if (VEC == 4) {
             float4 r[U];
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
         }
     }
     for (; s < k; ++s) {
+        if (ip[s] < 0) continue;
         const float* rp = tcol + ip[s] * (int64_t)D;
         const float w = Elem<CT>::load(cp, s);
 #pragma unroll

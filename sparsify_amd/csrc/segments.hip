@@ -31,7 +31,7 @@ static SegPlan make_plan(int64_t N, int64_t k, int64_t M) {
     SegPlan p;
     p.E = N * k;
     int bits = 1;
-    while ((1ll << bits) < M) ++bits;
+    while ((1ll << bits) < M + 1) ++bits;     // keys 0..M (M = sentinel bin)
     p.passes = (bits + SEG_MAX_DIGIT_BITS - 1) / SEG_MAX_DIGIT_BITS;
     p.digit_bits = (bits + p.passes - 1) / p.passes;
     p.tiles = cdiv(p.E, SEG_TILE);
@@ -47,10 +47,11 @@ static SegPlan make_plan(int64_t N, int64_t k, int64_t M) {
     return p;
 }
 
-// Out-of-range latent ids (a caller bug) are clamped so that they cannot turn into
-// out-of-bounds writes; in-range input is untouched.
+// Negative ids mark inactive slots (latent owned by another shard); they -- and any
+// out-of-range id -- sort into a sentinel bin M after all real latents, so no kernel that
+// walks segments 0..M-1 ever sees them. In-range input is untouched.
 __device__ __forceinline__ unsigned clamp_key(int64_t v, int64_t M) {
-    return (unsigned)(v < 0 ? 0 : (v >= M ? M - 1 : v));
+    return (unsigned)((v < 0 || v >= M) ? M : v);
 }
 
 template <bool FIRST>

@@ -24,11 +24,14 @@ namespace sphip {
 template <typename CT>
 __global__ __launch_bounds__(256) void seg_pack_kernel(const unsigned* __restrict__ perm,
                                                        const CT* __restrict__ coeff, int64_t E,
-                                                       uint2* __restrict__ packed) {
+                                                       const int* __restrict__ seg_begin, int M,
+                                                       uint2* __restrict__ packed, float* __restrict__ dcoeff) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p < E) {
         const unsigned e = perm[p];
         packed[p] = make_uint2(e, __float_as_uint(Elem<CT>::load(coeff, e)));
+        // entries past seg_begin[M] are inactive slots: no segment covers them
+        if (dcoeff != nullptr && p >= seg_begin[M]) dcoeff[e] = 0.f;
     }
 }
 
@@ -298,9 +301,9 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     uint2* packed = (uint2*)workspace;
     void* rows_sm = (char*)workspace + packed_bytes(N, k);
     if (coeff_dtype == SPHIP_F32)
-        hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, packed);
+        hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, dcoeff);
     else
-        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, packed);
+        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, dcoeff);
     const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" (tests)
     if (!dot && !(force && force[0] == 'f')) {
         const bool done = rows_dtype == SPHIP_F32

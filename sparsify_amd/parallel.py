@@ -1,0 +1,133 @@
+"""Multi-GPU pieces of the train step, one process per GPU over torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+Reference call sites: sparsify/trainer.py:457-468 (DDP gradient all-reduce), :614-628
+(maybe_all_reduce), :630-646 (distribute_modules plan), :358-380 (activation all-gathers).
+Latent-dim sharding (BASELINE.json configs[4]) does not exist in the reference; its
+contract here is "identical to the unsharded SparseCoder" (SURVEY.md section 8e).
+
+Everything in this file is device-agnostic collective plumbing on tensors that already
+exist; the compute stays in the HIP kernels."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def all_reduce_(x: Tensor, op: str = "mean") -> Tensor:
+    """In-place all-reduce with the reference's op names (trainer.py:614-628)."""
+    if world_size() == 1:
+        return x
+    if op == "sum":
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    elif op == "mean":
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        x /= world_size()
+    elif op == "max":
+        buf = x.view(torch.uint8) if x.dtype == torch.bool else x      # max is boolean "any"
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    else:
+        raise ValueError(f"Unknown reduction op '{op}'")
+    return x
+
+
+def module_plan(hookpoints: list[str], world: int) -> list[list[str]]:
+    """Contiguous blocks of hookpoints per rank (trainer.py:637-644)."""
+    per_rank, rem = divmod(len(hookpoints), world)
+    assert rem == 0, "Number of modules must be divisible by world size"
+    return [hookpoints[s: s + per_rank] for s in range(0, len(hookpoints), per_rank)]
+
+
+def all_gather_rows(x: Tensor) -> Tensor:
+    """(B, ...) on every rank -> (W*B, ...) (trainer.py:358-377)."""
+    if world_size() == 1:
+        return x
+    x = x.contiguous()
+    as_bool = x.dtype == torch.bool
+    src = x.view(torch.uint8) if as_bool else x
+    out = src.new_empty(src.shape[0] * world_size(), *src.shape[1:])
+    dist.all_gather_into_tensor(out, src)
+    return out.view(torch.bool) if as_bool else out
+
+
+class GradReducer:
+    """Averages dense gradients across ranks once per optimizer step.
+
+    The all-reduce of each parameter is launched asynchronously from a post-accumulate-grad
+    hook, i.e. as soon as that gradient is final, so with RCCL the 2 GiB W_dec.grad
+    transfer overlaps the encoder backward that is still running (the reference's DDP
+    wrapper reduces on every micro-step backward, trainer.py:457-468). ``should_reduce``
+    tells the hook whether the current backward is the last micro-step of the step."""
+
+    def __init__(self, params, should_reduce=lambda: True):
+        self.params = [p for p in params]
+        self.should_reduce = should_reduce
+        self.pending: list = []
+        self.handles = []
+        if world_size() > 1:
+            for p in self.params:
+                self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def _hook(self, p: Tensor):
+        if not self.should_reduce() or p.grad is None:
+            return
+        if dist.get_backend() == "nccl":
+            self.pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:
+            self.pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p))
+
+    def finish(self):
+        """Wait for every outstanding all-reduce (call before the optimizer step)."""
+        w = world_size()
+        for work, p in self.pending:
+            work.wait()
+            if p is not None:
+                p.grad /= w
+        self.pending.clear()
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles.clear()
+
+
+def broadcast_parameters(params, src: int = 0):
+    """What DDP does at wrap time (trainer.py:463): make replicas identical."""
+    if world_size() > 1:
+        for p in params:
+            dist.broadcast(p.data, src)
+
+
+# ------------------------------------------------------------------ latent-dim sharding
+def shard_range(num_latents: int, r: int | None = None, w: int | None = None) -> tuple[int, int]:
+    """Rank r owns latents [lo, hi) of W_enc / b_enc / W_dec."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    assert num_latents % w == 0, "num_latents must be divisible by the number of shards"
+    per = num_latents // w
+    return r * per, (r + 1) * per
+
+
+def gather_topk_candidates(local_vals: Tensor, local_idx: Tensor, lo: int) -> tuple[Tensor, Tensor]:
+    """All-gather every shard's k local candidates as (value, global index) pairs:
+    (N, k) per rank -> (N, W*k). W*N*k*(2..4 + 8) bytes on the wire."""
+    gidx = local_idx + lo
+    if world_size() == 1:
+        return local_vals, gidx
+    w = world_size()
+    N, k = local_vals.shape
+    vals = local_vals.new_empty(w * N, k)
+    idxs = gidx.new_empty(w * N, k)
+    dist.all_gather_into_tensor(vals, local_vals.contiguous())
+    dist.all_gather_into_tensor(idxs, gidx.contiguous())
+    return (vals.view(w, N, k).permute(1, 0, 2).reshape(N, w * k),
+            idxs.view(w, N, k).permute(1, 0, 2).reshape(N, w * k))

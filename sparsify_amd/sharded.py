@@ -1,0 +1,165 @@
+"""Latent-dim sharded sparse coder (BASELINE.json configs[4]: a 262144-latent transcoder with
+W_enc / W_dec split over 8 GPUs). New functionality -- the reference has no such mode; the
+contract is "identical to the unsharded SparseCoder up to ties" (SURVEY.md section 8e).
+
+Rank r owns latents [r*M/W, (r+1)*M/W) of encoder.weight, encoder.bias and W_dec; b_dec (and
+the token batch) are replicated. Per forward:
+  1. local pre-activations and local top-k (the same HIP kernels, on M/W latents);
+  2. all-gather of the k local (value, global index) candidates per token  [RCCL];
+  3. merge: top-k of the W*k candidates -> the global selection, identical on every rank;
+  4. partial decode of the selected latents this rank owns (other slots are inactive: index
+     -1, see sphip_gather_rows_weighted), then an all-reduce(SUM) of the partial
+     reconstructions [RCCL];
+  5. loss on the full reconstruction (replicated, cheap).
+Backward needs no collective at all: dL/d sae_out is replicated, every rank reduces the
+gradient rows of its own latents, and the gradient of a selected activation is needed only
+by its owner. The replicated b_dec is the one shared parameter; its gradient (D floats) is
+summed over ranks once per step by reduce_shared_grads().
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import ops, parallel
+from .config import SparseCoderConfig
+from .fused_encoder import _autocast_bf16, bf16_shadow
+from .sparse_coder import ForwardOutput, ResidualLoss
+from .utils import SparseDecode
+
+
+class _ShardedEncode(torch.autograd.Function):
+    """Local encoder GEMM + local top-k + candidate exchange + merge. Returns the merged
+    (values, global indices) and this rank's local view of the selection."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k: int, lo: int, hi: int, b_dec):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        low = _autocast_bf16()
+        if b_dec is not None:
+            rows, x_low = ops.center_cast(x2, b_dec.detach().contiguous(), want_f32=True, want_bf16=low)
+        else:
+            rows = x2
+            x_low = (x2 if x2.dtype == torch.bfloat16 else ops.center_cast(x2, None, False, True)[1]) if low else None
+        if low:
+            pre = ops.encoder_preacts(x_low, bf16_shadow(weight), bf16_shadow(bias))
+        else:
+            xf = rows if rows.dtype == torch.float32 else ops.center_cast(rows, None, True, False)[0]
+            pre = ops.encoder_preacts(xf, weight.detach().contiguous(), bias.detach().contiguous())
+        kk = min(k, pre.shape[1])
+        lv, li = ops.topk(pre, kk)
+        cand_v, cand_i = parallel.gather_topk_candidates(lv, li, lo)          # (N, W*kk)
+        mv, mpos = ops.topk(cand_v.contiguous(), k)                            # merge
+        gidx = cand_i.gather(1, mpos)
+        mine = (gidx >= lo) & (gidx < hi)
+        local_idx = torch.where(mine, gidx - lo, torch.full_like(gidx, -1))    # -1 = inactive slot
+        ops.forget_segments(local_idx)
+        ctx.save_for_backward(rows, weight, local_idx, b_dec)
+        ctx.k = k
+        ctx.mark_non_differentiable(gidx, local_idx)
+        ctx.set_materialize_grads(False)
+        return mv, gidx, local_idx
+
+    @staticmethod
+    def backward(ctx, grad_values, _g1, _g2):
+        rows, weight, local_idx, b_dec = ctx.saved_tensors
+        if grad_values is None:
+            return (None,) * 7
+        gv = grad_values.reshape(-1, ctx.k).contiguous()
+        seg = ops.cached_segments(local_idx, weight.shape[0])
+        gW, gb, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True)
+        g_bdec = None
+        if b_dec is not None and ctx.needs_input_grad[6]:
+            # this shard's part of -sum_n grad_x[n,:]; summed over shards by reduce_shared_grads()
+            g_bdec = ops.vec_mat(gb, weight.detach(), -1.0)
+        return None, gW, gb, None, None, None, g_bdec
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of the partial reconstructions; dL/dpartial = dL/dy on every rank."""
+
+    @staticmethod
+    def forward(ctx, partial):
+        out = partial.clone()
+        parallel.all_reduce_(out, "sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _ScaleGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, scale: float):
+        ctx.scale = scale
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
+class ShardedSparseCoder(nn.Module):
+    def __init__(self, d_in: int, cfg: SparseCoderConfig, device="cuda", dtype=torch.float32):
+        super().__init__()
+        self.cfg, self.d_in = cfg, d_in
+        self.num_latents = cfg.num_latents or d_in * cfg.expansion_factor
+        self.lo, self.hi = parallel.shard_range(self.num_latents)
+        m = self.hi - self.lo
+        # same init as SparseCoder.__init__ (sparse_coder.py:53-74), drawn for the full
+        # dictionary so that the shards are slices of the unsharded initialisation
+        full = nn.Linear(d_in, self.num_latents, device=device, dtype=dtype)
+        self.encoder = nn.Linear(d_in, m, device=device, dtype=dtype)
+        with torch.no_grad():
+            self.encoder.weight.copy_(full.weight[self.lo:self.hi])
+            self.encoder.bias.zero_()
+        if cfg.transcode:
+            self.W_dec = nn.Parameter(torch.zeros_like(self.encoder.weight.data))
+        else:
+            w = self.encoder.weight.data.clone()
+            if cfg.normalize_decoder:
+                w /= torch.norm(w, dim=1, keepdim=True) + torch.finfo(w.dtype).eps
+            self.W_dec = nn.Parameter(w)
+        self.b_dec = nn.Parameter(torch.zeros(d_in, dtype=dtype, device=device))
+        del full
+
+    @property
+    def dtype(self):
+        return self.encoder.weight.dtype
+
+    @torch.autocast("cuda", dtype=torch.bfloat16, enabled=torch.cuda.is_available())
+    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None) -> ForwardOutput:
+        if dead_mask is not None or self.cfg.multi_topk or self.cfg.activation != "topk":
+            raise NotImplementedError("the latent-sharded coder implements the plain top-k FVU step")
+        b_dec = None if self.cfg.transcode else self.b_dec
+        top_acts, top_indices, local_idx = _ShardedEncode.apply(
+            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.lo, self.hi, b_dec)
+        if y is None:
+            y = x
+        partial = SparseDecode.apply(local_idx, self.W_dec, top_acts.to(self.dtype), None)
+        # the decode-side gradient of the replicated b_dec is identical on every rank: keep 1/W
+        # of it here so that reduce_shared_grads() (one SUM over ranks, which also adds up the
+        # shard-local encoder-side terms) yields the unsharded gradient
+        sae_out = _AllReduceSum.apply(partial) + _ScaleGrad.apply(self.b_dec, 1.0 / parallel.world_size())
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        tv = ops.total_variance(y2)
+        fvu, _ = ResidualLoss.apply(sae_out, y, tv)
+        zero = sae_out.new_tensor(0.0)
+        return ForwardOutput(sae_out, top_acts, top_indices, fvu, zero, zero)
+
+    @torch.no_grad()
+    def reduce_shared_grads(self):
+        """Call once after backward: the only gradient that crosses shards is b_dec's (D floats)."""
+        if self.b_dec.grad is not None:
+            parallel.all_reduce_(self.b_dec.grad, "sum")
+
+    @torch.no_grad()
+    def set_decoder_norm_to_unit_norm(self):
+        ops.unit_norm_rows_(self.W_dec.data)
+        torch.autograd.graph.increment_version(self.W_dec)
+
+    @torch.no_grad()
+    def remove_gradient_parallel_to_decoder_directions(self):
+        ops.remove_parallel_grad_(self.W_dec.grad, self.W_dec.data)

@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from . import ops
+from . import ops, parallel
 from .config import TrainConfig
 from .muon import Muon
 from .schedule_free import ScheduleFreeWrapper
@@ -98,7 +98,9 @@ class Trainer:
                     name = f"{hook}/seed{seed}" if len(cfg.init_seeds) > 1 else hook
                     self.saes[name] = SparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
 
-        num_batches = max(len(source) // max(cfg.batch_size, 1), 1) if hasattr(source, "__len__") else 1
+        # the source yields one micro-batch per item (the reference counts sequences:
+        # len(dataset) // batch_size, trainer.py:90)
+        num_batches = max(len(source), 1) if hasattr(source, "__len__") else 1
         self._build_optimizers(num_batches)
 
         self.global_step = 0
@@ -183,35 +185,16 @@ class Trainer:
 
     def maybe_all_reduce(self, x: Tensor, op: str = "mean") -> Tensor:
         """trainer.py:614-628"""
-        if not dist.is_initialized() or self.cfg.distribute_modules or dist.get_world_size() == 1:
+        if not dist.is_initialized() or self.cfg.distribute_modules:
             return x
-        if op == "sum":
-            dist.all_reduce(x, op=dist.ReduceOp.SUM)
-        elif op == "mean":
-            dist.all_reduce(x, op=dist.ReduceOp.SUM)
-            x /= dist.get_world_size()
-        elif op == "max":
-            if x.dtype == torch.bool:
-                buf = x.view(torch.uint8)
-                dist.all_reduce(buf, op=dist.ReduceOp.MAX)
-            else:
-                dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        else:
-            raise ValueError(f"Unknown reduction op '{op}'")
-        return x
+        return parallel.all_reduce_(x, op)
 
     def distribute_modules(self):
         """trainer.py:630-646: contiguous blocks of hookpoints per rank."""
         if not self.cfg.distribute_modules:
             self.module_plan = []
             return
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        layers_per_rank, rem = divmod(len(self.cfg.hookpoints), world)
-        assert rem == 0, "Number of modules must be divisible by world size"
-        self.module_plan = [
-            self.cfg.hookpoints[start: start + layers_per_rank]
-            for start in range(0, len(self.cfg.hookpoints), layers_per_rank)
-        ]
+        self.module_plan = parallel.module_plan(self.cfg.hookpoints, parallel.world_size())
 
     def local_hookpoints(self) -> list[str]:
         if self.module_plan:
@@ -220,55 +203,31 @@ class Trainer:
         return self.cfg.hookpoints
 
     def _install_grad_hooks(self):
-        """Overlap the dense-gradient all-reduce with the rest of the backward: each
-        parameter's all-reduce is launched (async, RCCL stream) as soon as its gradient has
-        been accumulated on the last micro-step of an optimizer step."""
+        """See parallel.GradReducer: async all-reduce per parameter on the last micro-step."""
         if self._hooks_installed or not self.ddp:
             return
-        world = dist.get_world_size()
-
-        def hook(p: Tensor):
-            if (self.global_step + 1) % self.cfg.grad_acc_steps != 0:
-                return
-            if dist.get_backend() == "nccl":
-                self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True))
-            else:
-                w = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True)
-                self._pending.append((w, p, world))
-
-        for sae in self.saes.values():
-            for p in sae.parameters():
-                p.register_post_accumulate_grad_hook(hook)
+        params = [p for sae in self.saes.values() for p in sae.parameters()]
+        parallel.broadcast_parameters(params)
+        self._reducer = parallel.GradReducer(
+            params, lambda: (self.global_step + 1) % self.cfg.grad_acc_steps == 0)
         self._hooks_installed = True
 
     def _finish_grad_reduce(self):
-        for item in self._pending:
-            if isinstance(item, tuple):
-                w, p, world = item
-                w.wait()
-                p.grad /= world
-            else:
-                item.wait()
-        self._pending.clear()
+        if getattr(self, "_reducer", None) is not None:
+            self._reducer.finish()
 
     # ------------------------------------------------------------------ the hook body (trainer.py:340-447)
     def train_on_activations(self, name: str, inputs: Tensor | None, outputs: Tensor, mask: Tensor | None = None):
         cfg = self.cfg
         hook_name = name.partition("/")[0]
 
-        if cfg.distribute_modules and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            gathered = outputs.new_empty(outputs.shape[0] * world, *outputs.shape[1:])
-            dist.all_gather_into_tensor(gathered, outputs.contiguous())
-            outputs = gathered
+        if cfg.distribute_modules and parallel.world_size() > 1:
+            # trainer.py:358-380: every rank contributes its batch, only the owner trains
+            outputs = parallel.all_gather_rows(outputs)
             if cfg.sae.transcode:
-                gi = inputs.new_empty(inputs.shape[0] * world, *inputs.shape[1:])
-                dist.all_gather_into_tensor(gi, inputs.contiguous())
-                inputs = gi
+                inputs = parallel.all_gather_rows(inputs)
             if mask is not None:
-                gm = mask.new_empty(mask.shape[0] * world, *mask.shape[1:])
-                dist.all_gather_into_tensor(gm.view(torch.uint8), mask.contiguous().view(torch.uint8))
-                mask = gm
+                mask = parallel.all_gather_rows(mask)
             if hook_name not in self.module_plan[dist.get_rank()]:
                 return None
 

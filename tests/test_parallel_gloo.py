@@ -1,0 +1,121 @@
+"""World-size-2 tests of the multi-GPU plumbing (sparsify_amd/parallel.py) on CPU with gloo.
+They cover what the N>1 bench path and the Trainer use: reductions with the reference's op
+names, the distribute_modules plan and activation gathers, the once-per-step async gradient
+averaging, and the candidate exchange of the latent-sharded top-k."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def launch(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _reductions(rank, world):
+    from sparsify_amd import parallel as P
+    x = torch.full((4,), float(rank + 1))
+    mean = P.all_reduce_(x.clone(), "mean")
+    tot = P.all_reduce_(x.clone(), "sum")
+    fired = torch.zeros(6, dtype=torch.bool)
+    fired[rank] = True
+    fired[5] = rank == 1
+    P.all_reduce_(fired, "max")
+    rows = torch.arange(6, dtype=torch.float32).reshape(2, 3) + 10 * rank
+    gathered = P.all_gather_rows(rows)
+    mask = P.all_gather_rows(torch.tensor([[True, False]]) if rank == 0 else torch.tensor([[False, False]]))
+    with pytest.raises(ValueError):
+        P.all_reduce_(x, "median")
+    return dict(mean=mean, tot=tot, fired=fired, gathered=gathered, mask=mask, lo_hi=P.shard_range(8))
+
+
+def test_reductions_and_gathers():
+    out = launch(_reductions)
+    for r in out:
+        assert torch.equal(r["mean"], torch.full((4,), 1.5))
+        assert torch.equal(r["tot"], torch.full((4,), 3.0))
+        assert r["fired"].tolist() == [True, True, False, False, False, True]
+        assert torch.equal(r["gathered"], torch.tensor([[0., 1, 2], [3, 4, 5], [10, 11, 12], [13, 14, 15]]))
+        assert r["mask"].dtype == torch.bool and r["mask"].tolist() == [[True, False], [False, False]]
+    assert out[0]["lo_hi"] == (0, 4) and out[1]["lo_hi"] == (4, 8)
+
+
+def test_module_plan():
+    from sparsify_amd import parallel as P
+    hooks = [f"layers.{i}" for i in range(8)]
+    assert P.module_plan(hooks, 4) == [hooks[0:2], hooks[2:4], hooks[4:6], hooks[6:8]]   # trainer.py:641-644
+    with pytest.raises(AssertionError):
+        P.module_plan(hooks, 3)
+
+
+def _grad_reducer(rank, world):
+    from sparsify_amd import parallel as P
+    torch.manual_seed(0)
+    model = torch.nn.Linear(5, 3)
+    P.broadcast_parameters(model.parameters())
+    state = {"micro": 0}
+    acc = 2
+    red = P.GradReducer(model.parameters(), lambda: (state["micro"] + 1) % acc == 0)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(world * acc, 4, 5, generator=g)
+    for micro in range(acc):
+        state["micro"] = micro
+        x = data[rank * acc + micro]
+        (model(x).pow(2).mean() / acc).backward()
+        if micro == 0:
+            assert not red.pending            # no collective before the last micro-step
+    red.finish()
+    return [p.grad.clone() for p in model.parameters()], data
+
+
+def test_grad_reducer_matches_global_average():
+    out = launch(_grad_reducer)
+    (g0, data), (g1, _) = out
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)               # replicas hold identical gradients
+    torch.manual_seed(0)
+    model = torch.nn.Linear(5, 3)
+    loss = sum(model(data[i]).pow(2).mean() / 2 for i in range(4)) / 2
+    loss.backward()
+    for a, p in zip(g0, model.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-6, atol=1e-7)
+
+
+def _sharded_topk(rank, world):
+    from sparsify_amd import parallel as P
+    torch.manual_seed(7)
+    N, M, k = 16, 64, 5
+    pre = torch.rand(N, M)                         # same on both ranks (replicated tokens)
+    lo, hi = P.shard_range(M)
+    lv, li = pre[:, lo:hi].topk(k, dim=-1)
+    vals, gidx = P.gather_topk_candidates(lv, li, lo)
+    assert vals.shape == (N, world * k)
+    mv, mpos = vals.topk(k, dim=-1)                # merge (ops.topk on the GPU path)
+    midx = gidx.gather(1, mpos)
+    ref = pre.topk(k, dim=-1)
+    return torch.equal(mv, ref.values) and torch.equal(midx.sort(-1).values, ref.indices.sort(-1).values)
+
+
+def test_latent_sharded_topk_merge_equals_global_topk():
+    assert all(launch(_sharded_topk))
