@@ -81,17 +81,27 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="fp32 activations / no autocast (not the headline)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if os.environ.get("SPHIP_HANG_DUMP"):      # debugging aid: dump all stacks if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SPHIP_HANG_DUMP"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from sparsify_amd import SparseCoderConfig, TrainConfig, ops
     from sparsify_amd.trainer import SyntheticActivations, Trainer
@@ -132,7 +142,8 @@ def main():
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        from sparsify_amd import parallel
+        parallel.all_reduce_(t, "max")
     elapsed = float(t.item())
 
     if rank == 0:

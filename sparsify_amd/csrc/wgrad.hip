@@ -189,12 +189,17 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
+    // Software pipeline: the packed entries of batch b+1 are requested before the row pieces
+    // of batch b are consumed, so a batch costs one L2 round trip instead of two.
     constexpr int U = 4;
+    uint2 nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nxt[u] = (beg + u < end) ? packed[beg + u] : make_uint2(0u, 0u);
     for (int p = beg; p < end; p += U) {
         uint2 pk[U];
         float v[U][C];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pk[u] = (p + u < end) ? packed[p + u] : make_uint2(0u, 0u);
+        for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if ((p + u < end) && live) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                 for (int c = 0; c < C; ++c) v[u][c] = 0.f;
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = (p + U + u < end) ? packed[p + U + u] : make_uint2(0u, 0u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (p + u < end) {     // keeps the exact sequential fma chain of the full-row kernel

@@ -23,21 +23,47 @@ def rank() -> int:
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def _host_staged(x: Tensor) -> bool:
+    """gloo moves device tensors through its own pinned staging buffers and streams; that path
+    stalls intermittently on ROCm when ranks share one GPU (single-GPU rehearsals of the
+    multi-rank code). Device tensors under gloo are therefore staged through host memory here;
+    under RCCL ("nccl") they never leave the device."""
+    return x.is_cuda and dist.get_backend() != "nccl"
+
+
+def _all_reduce_raw(x: Tensor, op) -> None:
+    if _host_staged(x):
+        h = x.cpu()
+        dist.all_reduce(h, op=op)
+        x.copy_(h)
+    else:
+        dist.all_reduce(x, op=op)
+
+
 def all_reduce_(x: Tensor, op: str = "mean") -> Tensor:
     """In-place all-reduce with the reference's op names (trainer.py:614-628)."""
     if world_size() == 1:
         return x
     if op == "sum":
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        _all_reduce_raw(x, dist.ReduceOp.SUM)
     elif op == "mean":
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        _all_reduce_raw(x, dist.ReduceOp.SUM)
         x /= world_size()
     elif op == "max":
         buf = x.view(torch.uint8) if x.dtype == torch.bool else x      # max is boolean "any"
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+        _all_reduce_raw(buf, dist.ReduceOp.MAX)
     else:
         raise ValueError(f"Unknown reduction op '{op}'")
     return x
+
+
+def _all_gather_raw(out: Tensor, src: Tensor) -> None:
+    if _host_staged(src):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, src.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, src)
 
 
 def module_plan(hookpoints: list[str], world: int) -> list[list[str]]:
@@ -55,56 +81,45 @@ def all_gather_rows(x: Tensor) -> Tensor:
     as_bool = x.dtype == torch.bool
     src = x.view(torch.uint8) if as_bool else x
     out = src.new_empty(src.shape[0] * world_size(), *src.shape[1:])
-    dist.all_gather_into_tensor(out, src)
+    _all_gather_raw(out, src)
     return out.view(torch.bool) if as_bool else out
 
 
 class GradReducer:
-    """Averages dense gradients across ranks once per optimizer step.
+    """Averages dense gradients across ranks once per optimizer step (the reference's DDP
+    wrapper reduces on every micro-step backward, trainer.py:457-468, because it never uses
+    no_sync()). ``finish()`` is called right before the optimizer step: one all-reduce per
+    parameter, enqueued in parameter order on every rank; with RCCL the calls are
+    stream-ordered (no host sync) and run back to back over all xGMI links."""
 
-    The all-reduce of each parameter is launched asynchronously from a post-accumulate-grad
-    hook, i.e. as soon as that gradient is final, so with RCCL the 2 GiB W_dec.grad
-    transfer overlaps the encoder backward that is still running (the reference's DDP
-    wrapper reduces on every micro-step backward, trainer.py:457-468). ``should_reduce``
-    tells the hook whether the current backward is the last micro-step of the step."""
-
-    def __init__(self, params, should_reduce=lambda: True):
+    def __init__(self, params):
         self.params = [p for p in params]
-        self.should_reduce = should_reduce
-        self.pending: list = []
-        self.handles = []
-        if world_size() > 1:
-            for p in self.params:
-                self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
-
-    def _hook(self, p: Tensor):
-        if not self.should_reduce() or p.grad is None:
-            return
-        if dist.get_backend() == "nccl":
-            self.pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, async_op=True), None))
-        else:
-            self.pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p))
 
     def finish(self):
-        """Wait for every outstanding all-reduce (call before the optimizer step)."""
         w = world_size()
-        for work, p in self.pending:
-            work.wait()
-            if p is not None:
+        if w == 1:
+            return
+        avg = dist.get_backend() == "nccl"
+        for p in self.params:
+            if p.grad is None:
+                continue
+            if avg:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+            else:
+                _all_reduce_raw(p.grad, dist.ReduceOp.SUM)
                 p.grad /= w
-        self.pending.clear()
-
-    def remove(self):
-        for h in self.handles:
-            h.remove()
-        self.handles.clear()
 
 
 def broadcast_parameters(params, src: int = 0):
     """What DDP does at wrap time (trainer.py:463): make replicas identical."""
     if world_size() > 1:
         for p in params:
-            dist.broadcast(p.data, src)
+            if _host_staged(p.data):
+                h = p.data.cpu()
+                dist.broadcast(h, src)
+                p.data.copy_(h)
+            else:
+                dist.broadcast(p.data, src)
 
 
 # ------------------------------------------------------------------ latent-dim sharding
@@ -127,7 +142,7 @@ def gather_topk_candidates(local_vals: Tensor, local_idx: Tensor, lo: int) -> tu
     N, k = local_vals.shape
     vals = local_vals.new_empty(w * N, k)
     idxs = gidx.new_empty(w * N, k)
-    dist.all_gather_into_tensor(vals, local_vals.contiguous())
-    dist.all_gather_into_tensor(idxs, gidx.contiguous())
+    _all_gather_raw(vals, local_vals.contiguous())
+    _all_gather_raw(idxs, gidx.contiguous())
     return (vals.view(w, N, k).permute(1, 0, 2).reshape(N, w * k),
             idxs.view(w, N, k).permute(1, 0, 2).reshape(N, w * k))

@@ -9,9 +9,8 @@ a HuggingFace model to produce the activations -- the Trainer consumes an
 ``ActivationSource`` (any iterable of {hookpoint: outputs | (inputs, outputs)} batches).
 
 MI355X-first differences, all value-preserving:
-  * gradients are all-reduced (RCCL) once per optimizer step, launched from
-    post-accumulate hooks so W_dec.grad's transfer overlaps the encoder backward, instead of
-    DDP's all-reduce on every micro-step backward (trainer.py:457-468 has no no_sync());
+  * gradients are all-reduced (RCCL) once per optimizer step instead of DDP's all-reduce on
+    every micro-step backward (trainer.py:457-468 has no no_sync());
   * logged scalars stay on the device until they are logged (the reference calls float()
     on three all-reduced scalars per hook call, trainer.py:433-441);
   * with plain SignSGD the projected gradient and the sign step of W_dec are one kernel.
@@ -203,13 +202,12 @@ class Trainer:
         return self.cfg.hookpoints
 
     def _install_grad_hooks(self):
-        """See parallel.GradReducer: async all-reduce per parameter on the last micro-step."""
+        """See parallel.GradReducer: one gradient average per optimizer step."""
         if self._hooks_installed or not self.ddp:
             return
         params = [p for sae in self.saes.values() for p in sae.parameters()]
         parallel.broadcast_parameters(params)
-        self._reducer = parallel.GradReducer(
-            params, lambda: (self.global_step + 1) % self.cfg.grad_acc_steps == 0)
+        self._reducer = parallel.GradReducer(params)
         self._hooks_installed = True
 
     def _finish_grad_reduce(self):
