@@ -1,0 +1,31 @@
+"""Times sphip_encoder_preacts alone at the headline shape (bf16, N=16384, D=4096, M=131072).
+Usage: python benchmarks/gemm_bench.py [diag ...]   (diag = SPHIP_GEMM_DIAG values to sweep; non-zero
+values need a library built with `make -C sparsify_amd/csrc clean all DIAG=1`)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparsify_amd import ops  # noqa: E402
+
+N, D, M = 16384, 4096, 131072
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(N, D, device=dev, generator=g).to(torch.bfloat16)
+W = (torch.randn(M, D, device=dev, generator=g) / 64).to(torch.bfloat16)
+b = torch.zeros(M, device=dev, dtype=torch.bfloat16)
+diags = sys.argv[1:] or ["0"]
+for dg in diags:
+    os.environ["SPHIP_GEMM_DIAG"] = dg
+    for _ in range(3):
+        ops.encoder_preacts(x, W, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.encoder_preacts(x, W, b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"diag={dg} {ms:.3f} ms  {2.0 * N * D * M / ms / 1e9:.0f} TFLOP/s", flush=True)

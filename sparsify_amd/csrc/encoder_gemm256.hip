@@ -1,34 +1,34 @@
 // Encoder pre-activations, large-shape bf16 kernel: 256(latent) x 256(token) x 64(K) tile,
 // 512 threads = 8 waves (2 latent groups x 4 token groups, 128 x 64 outputs per wave),
-// v_mfma_f32_16x16x32_bf16, operands staged by LDS-DMA (global_load_lds_dwordx4) into a
-// 128 KiB double-buffered image, counted vmcnt waits and raw s_barriers so two tiles of
-// staging stay in flight across barriers, and the two wave groups that share a SIMD run
-// staggered by one barrier (one group's MFMA segment overlaps the other's LDS-read /
-// DMA-issue segment).
+// v_mfma_f32_16x16x32_bf16, operands staged by LDS-DMA (buffer_load_dwordx4 ... lds) into a
+// 128 KiB double-buffered image, counted vmcnt waits and raw s_barriers so up to a K tile of
+// staging stays in flight across barriers, and the two wave groups that share a SIMD run
+// staggered by one barrier (one group's MFMA segment overlaps the other's LDS-read segment).
 // Reference semantics: FusedEncoder.forward, sparsify/fused_encoder.py:29, under bf16
 // autocast (sparse_coder.py:205-209); same contract as encoder_gemm.hip.
 //
-// LDS image. A K tile of one operand (256 rows x 128 B of K) is kept as two "half tiles" of
-// 128 rows, split NOT by wave group but by when they are consumed:
-//     W-lo : rows  [g*128 +  0, g*128 +  64)  of both latent groups g   -> read in phase 0
-//     W-hi : rows  [g*128 + 64, g*128 + 128)                            -> read in phase 2
-//     X-lo : rows  [n*64  +  0, n*64  +  32)  of the four token groups n -> read in phase 0
-//     X-hi : rows  [n*64  + 32, n*64  +  64)                            -> read in phase 1
-// so every half tile is read in exactly one phase of the K tile. A half tile is a linear
-// [128 rows][8 chunks of 16 B] array whose chunk index is XOR-swizzled with (row>>1)&7
-// (conflict-free ds_read_b128 for the 16x16x32 fragment shape). LDS-DMA writes linearly
-// (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE address.
+// LDS image of one K tile (64 KiB, two of them):
+//     X    : 256 token rows x 128 B                                         -> read in L0
+//     W-lo : rows [g*128 +  0, g*128 +  64) of both latent groups g (16 KiB) -> read in L0
+//     W-hi : rows [g*128 + 64, g*128 + 128)                        (16 KiB) -> read in L1
+// Every region is a linear [rows][8 chunks of 16 B] array whose chunk index is XOR-swizzled
+// with (row>>1)&7 (conflict-free ds_read_b128 for the 16x16x32 fragment shape). LDS-DMA
+// writes linearly (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE
+// address.
 //
-// Schedule per K tile t (4 phases, each = LOAD segment | barrier | MFMA segment | barrier):
-//     phase 0: ds_read W-lo(8) + X-lo(4) | DMA X-lo(t+1) | 16 MFMA (w-lo x x-lo)
-//     phase 1: ds_read X-hi(4)           | DMA W-lo(t+1) | 16 MFMA (w-lo x x-hi)
-//     phase 2: ds_read W-hi(8)           | DMA X-hi(t+1) | 16 MFMA (w-hi x x-hi)
-//     phase 3: -                         | DMA W-hi(t+1) | 16 MFMA (w-hi x x-lo)
-// RAW: each wave retires the DMA of the half tile read in the NEXT phase with a counted
-// s_waitcnt vmcnt(4) at the end of its LOAD segment, i.e. before a barrier that every wave
-// passes before the earliest reader (the un-delayed wave group) starts that phase.
-// WAR: a half tile is overwritten 4 phases after the phase that read it.
+// Schedule per K tile t: four segments, each closed by a barrier (code segment s = 4t + i):
+//     L0: ds_read X(t) (8) + W-lo(t) (8)        | vmcnt(6): W-hi(t) landed
+//     M0: DMA W-hi(t+1)                         | 32 MFMA (w-lo x x)
+//     L1: ds_read W-hi(t) (8)                   | vmcnt(2): X(t+1), W-lo(t+1) landed
+//     M1: DMA X(t+2), W-lo(t+2)                 | 32 MFMA (w-hi x x)
+// Wave group 1 runs one barrier behind group 0, so while one group is in an M segment its
+// SIMD partner is in an L segment. With that skew:
+// RAW: a region read in code segment r is awaited (own vmcnt) in a segment <= r-2, so every
+//      wave has passed a barrier after its wait before the leading group starts r.
+// WAR: a region read in code segment r is overwritten by DMA issued in a segment >= r+3,
+//      after the lagging group has completed (lgkmcnt) its reads of r.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sphip {
 
@@ -37,33 +37,35 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int G_TILE = 256;
-constexpr int G_BK = 64;                    // bf16 elements per K tile (128 B)
-constexpr int HALF_BYTES = 128 * 128;       // 16 KiB
-constexpr int BUF_BYTES = 4 * HALF_BYTES;   // one K tile of both operands: 64 KiB
-constexpr int G_LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
-// half-tile slots inside a buffer
-constexpr int H_XLO = 0, H_WLO = 1, H_XHI = 2, H_WHI = 3;
+// MFMA groups of 4 issued after an M segment's closing barrier (raising the barrier hides its
+// release latency under the last MFMAs): measured 0 -> 12.1 ms, 1 -> 12.0 ms, 2 -> 12.6 ms
+constexpr int EARLY = 0;
+constexpr int G_BK = 64;                      // bf16 elements per K tile (128 B)
+constexpr int R_X = 0;                        // region offsets inside a K-tile buffer
+constexpr int R_WLO = 256 * 128;              // 32 KiB
+constexpr int R_WHI = R_WLO + 128 * 128;      // 48 KiB
+constexpr int BUF_BYTES = R_WHI + 128 * 128;  // 64 KiB
+constexpr int EPI_ROW = 272;                  // epilogue staging: 128 bf16 + 16 B pad per token row
+constexpr int EPI_WAVE = 64 * EPI_ROW;        // 17 KiB per wave
+constexpr int G_LDS_BYTES = (2 * BUF_BYTES > 8 * EPI_WAVE) ? 2 * BUF_BYTES : 8 * EPI_WAVE;
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
 #define SPHIP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 __device__ __forceinline__ void seg_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool RELU>
+template <bool RELU, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* __restrict__ X,
                                                                  const bf16_t* __restrict__ W,
                                                                  const bf16_t* __restrict__ bias,
                                                                  bf16_t* __restrict__ P, int N, int D, int M,
-                                                                 int tilesM, int tilesN) {
+                                                                 int tilesM, int tilesN, unsigned* dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         tm = (int)(first + within % gsize);
         tn = (int)(within / gsize);
     }
-    const int m0 = tm * G_TILE, n0 = tn * G_TILE;
+    const int m0 = (DIAG & 16) ? (tm & 1) * G_TILE : tm * G_TILE, n0 = (DIAG & 16) ? (tn & 1) * G_TILE : tn * G_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -89,37 +91,46 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
     const int r16 = lane & 15, q4 = lane >> 4;
     const int kTiles = D / G_BK;
 
-    // ---- staging: thread owns chunks c = tid + 512*i (i = 0,1) of every half tile
-    const bf16_t* src[4][2];
-    int dst_off[2];
+    // ---- staging: thread owns 16-B chunk c = tid + 512*i of a region (X: i < 4, W halves: i < 2).
+    // hr = c >> 3 is the region row; (hr >> 1) & 7 does not depend on i (rows advance by 64).
+    // Sources go through buffer descriptors of the two operand tiles: one per-lane byte offset
+    // (row hr0, swizzled chunk) serves every piece, the piece's row block and the K tile are
+    // a scalar offset, and rows past the end of X / W read as zeros (descriptor range check).
+    const int hr0 = tid >> 3;
+    const int logical = (tid & 7) ^ ((hr0 >> 1) & 7);            // source chunk for this LDS slot
+    const int dst0 = 64 * wave * 16;                             // wave-uniform base of the 1 KiB piece
+    const unsigned voff = (unsigned)hr0 * (unsigned)D * 2u + (unsigned)logical * 16u;
+    const unsigned rowblk = 64u * (unsigned)D * 2u;              // bytes of a 64-row block
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(X + (int64_t)n0 * D), 0, (int)(min(G_TILE, N - n0) * D * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(W + (int64_t)m0 * D), 0, (int)(min(G_TILE, M - m0) * D * 2), 0x00020000);
+    auto stage_x1 = [&](int t, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(smem + (t & 1) * BUF_BYTES + R_X + dst0 + 512 * 16 * i),
+                                                 16, voff, (unsigned)t * (G_BK * 2) + (unsigned)i * rowblk, 0, 0);
+    };
+    // W-lo piece i holds tile rows i*128 + [0,64), W-hi piece i rows i*128 + 64 + [0,64)
+    auto stage_w1 = [&](int hi, int t, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            wrsrc, (lptr_t)(smem + (t & 1) * BUF_BYTES + (hi ? R_WHI : R_WLO) + dst0 + 512 * 16 * i), 16, voff,
+            (unsigned)t * (G_BK * 2) + (unsigned)(2 * i + hi) * rowblk, 0, 0);
+    };
+    auto stage_x = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 512 * i;
-        const int hr = c >> 3;                                   // half-tile row 0..127
-        const int logical = (c & 7) ^ ((hr >> 1) & 7);           // source chunk for this LDS slot
-        dst_off[i] = (512 * i + 64 * wave) * 16;                 // wave-uniform LDS base of the 1 KiB piece
-        const int wrow_lo = (hr >> 6) * 128 + (hr & 63);         // W tile row of W-lo[hr]
-        const int xrow_lo = (hr >> 5) * 64 + (hr & 31);          // X tile row of X-lo[hr]
-        const int gm_lo = min(m0 + wrow_lo, M - 1), gm_hi = min(m0 + wrow_lo + 64, M - 1);
-        const int gn_lo = min(n0 + xrow_lo, N - 1), gn_hi = min(n0 + xrow_lo + 32, N - 1);
-        src[H_XLO][i] = X + (int64_t)gn_lo * D + logical * 8;
-        src[H_XHI][i] = X + (int64_t)gn_hi * D + logical * 8;
-        src[H_WLO][i] = W + (int64_t)gm_lo * D + logical * 8;
-        src[H_WHI][i] = W + (int64_t)gm_hi * D + logical * 8;
-    }
-    auto stage = [&](int half, int t) {
-        char* base = smem + (t & 1) * BUF_BYTES + half * HALF_BYTES;
-        dma16(src[half][0] + (int64_t)t * G_BK, base + dst_off[0]);
-        dma16(src[half][1] + (int64_t)t * G_BK, base + dst_off[1]);
+        for (int i = 0; i < 4; ++i) stage_x1(t, i);
+    };
+    auto stage_w = [&](int hi, int t) {
+        stage_w1(hi, t, 0);
+        stage_w1(hi, t, 1);
     };
 
     // ---- fragment reads. They are issued from inline asm: hipcc's waitcnt pass would put an
     // s_waitcnt vmcnt(0) in front of every compiler-visible ds_read that follows an LDS-DMA
     // (it cannot tell which DMA a read depends on) and drain the staging pipeline each
-    // phase. The reads' completion is awaited by the explicit lgkmcnt(0) below, which names
+    // segment. The reads' completion is awaited by the explicit lgkmcnt(0) below, which names
     // every destination register so no consumer can be scheduled above it.
-    // Per-lane byte address inside a half tile, k-step ks: chunk = 4*ks + q4. The row part
-    // of the XOR ((hr>>1)&7 = (r16>>1)&7) does not depend on the 16-row tile index, so the
+    // Per-lane byte address inside a region, k-step ks: chunk = 4*ks + q4. The row part of
+    // the XOR ((row>>1)&7 = (r16>>1)&7) does not depend on the 16-row tile index, so the
     // tiles of a sub-block are reached with immediate offsets (tile stride 16*128 B).
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const int swz = (r16 >> 1) & 7;
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         wbase[ks] = lds0 + (wm * 64 + r16) * 128 + (((4 * ks + q4) ^ swz) << 4);
-        xbase[ks] = lds0 + (wn * 32 + r16) * 128 + (((4 * ks + q4) ^ swz) << 4);
+        xbase[ks] = lds0 + (wn * 64 + r16) * 128 + (((4 * ks + q4) ^ swz) << 4);
     }
 
     f32x4_t acc[8][4];
@@ -136,133 +147,203 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    u32x4_t wf[4][2], xlo[2][2], xhi[2][2];
+    u32x4_t wf[4][2], xf[4][2];
+    unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tlast = 0;
+#define SPHIP_STAMP(i)                                                        \
+    if (DIAG & 32) {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned now_ = (unsigned)__builtin_readcyclecounter();         \
+        tacc[i] += now_ - tlast;                                              \
+        tlast = now_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
 
 #define SPHIP_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define SPHIP_READ_W(HALF)                                              \
-    SPHIP_DSR(wf[0][0], wa0, (HALF) * HALF_BYTES + 0 * 2048);           \
-    SPHIP_DSR(wf[0][1], wa1, (HALF) * HALF_BYTES + 0 * 2048);           \
-    SPHIP_DSR(wf[1][0], wa0, (HALF) * HALF_BYTES + 1 * 2048);           \
-    SPHIP_DSR(wf[1][1], wa1, (HALF) * HALF_BYTES + 1 * 2048);           \
-    SPHIP_DSR(wf[2][0], wa0, (HALF) * HALF_BYTES + 2 * 2048);           \
-    SPHIP_DSR(wf[2][1], wa1, (HALF) * HALF_BYTES + 2 * 2048);           \
-    SPHIP_DSR(wf[3][0], wa0, (HALF) * HALF_BYTES + 3 * 2048);           \
-    SPHIP_DSR(wf[3][1], wa1, (HALF) * HALF_BYTES + 3 * 2048)
-#define SPHIP_READ_X(XF, HALF)                                          \
-    SPHIP_DSR(XF[0][0], xa0, (HALF) * HALF_BYTES + 0 * 2048);           \
-    SPHIP_DSR(XF[0][1], xa1, (HALF) * HALF_BYTES + 0 * 2048);           \
-    SPHIP_DSR(XF[1][0], xa0, (HALF) * HALF_BYTES + 1 * 2048);           \
-    SPHIP_DSR(XF[1][1], xa1, (HALF) * HALF_BYTES + 1 * 2048)
-#define SPHIP_LGKM0_W()                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                   \
-                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]),         \
-                   "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]))
-#define SPHIP_LGKM0_X(XF) \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(XF[0][0]), "+v"(XF[0][1]), "+v"(XF[1][0]), "+v"(XF[1][1]))
+#define SPHIP_READ4(F, REGION)                          \
+    SPHIP_DSR(F[0][0], a0, (REGION) + 0 * 2048);        \
+    SPHIP_DSR(F[0][1], a1, (REGION) + 0 * 2048);        \
+    SPHIP_DSR(F[1][0], a0, (REGION) + 1 * 2048);        \
+    SPHIP_DSR(F[1][1], a1, (REGION) + 1 * 2048);        \
+    SPHIP_DSR(F[2][0], a0, (REGION) + 2 * 2048);        \
+    SPHIP_DSR(F[2][1], a1, (REGION) + 2 * 2048);        \
+    SPHIP_DSR(F[3][0], a0, (REGION) + 3 * 2048);        \
+    SPHIP_DSR(F[3][1], a1, (REGION) + 3 * 2048)
+#define SPHIP_LGKM0(F)                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                           \
+                 : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]),      \
+                   "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1]))
 
-    auto mma = [&](int mbase, int nbase, const u32x4_t (&xf)[2][2]) {
+    // 32 MFMAs of one M segment; the segment's DMA instructions (NDMA of them, issued by
+    // dma(j)) are spread between the MFMAs so that their issue cost (M0 write, address add,
+    // VMEM issue: ~45 cycles each when issued back to back at the head) hides under the
+    // matrix pipe instead of delaying the first MFMA.
+    auto mma = [&](int mbase, int ndma, auto dma) {
+        if (DIAG & 2) {
+            for (int j = 0; j < ndma; ++j) dma(j);
+            seg_barrier();
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mbase + mt][nbase + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mbase + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, wf[mt][ks]), __builtin_bit_cast(bf16x8_t, xf[nt][ks]),
-                        acc[mbase + mt][nbase + nt], 0, 0, 0);
+                        acc[mbase + mt][nt], 0, 0, 0);
+                const int j = ks * 4 + mt;
+                if (j < ndma) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma(j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the segment's closing barrier is raised early: its release latency then
+                // overlaps this wave's last MFMAs instead of idling the matrix pipe
+                if (j == 7 - EARLY) seg_barrier();
+            }
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // ---- prologue: K tile 0 completely, first two half tiles retired
-    stage(H_XLO, 0);
-    stage(H_WLO, 0);
-    stage(H_XHI, 0);
-    stage(H_WHI, 0);
-    SPHIP_VMCNT(4);
+    // ---- prologue: K tile 0 completely plus X / W-lo of K tile 1; X(0), W-lo(0) retired
+    stage_x(0);
+    stage_w(0, 0);
+    stage_w(1, 0);
+    if (kTiles > 1) {
+        stage_x(1);
+        stage_w(0, 1);
+        SPHIP_VMCNT(8);
+    } else {
+        SPHIP_VMCNT(2);
+    }
     seg_barrier();
     if (wm == 1) seg_barrier();          // stagger the second wave group by one barrier
+    if (DIAG & 32) tlast = (unsigned)__builtin_readcyclecounter();
 
-    // One K tile. NEXT: stage tile t+1 while computing tile t.
-    // Outstanding DMA (per wave, in issue order) at each wait is listed on the right.
-#define SPHIP_KTILE(NEXT, WAIT_A, WAIT_B, WAIT_C)                                                        \
-    {                                                                                                   \
-        const unsigned bo = (unsigned)(t & 1) * BUF_BYTES;                                              \
-        const unsigned wa0 = wbase[0] + bo, wa1 = wbase[1] + bo, xa0 = xbase[0] + bo, xa1 = xbase[1] + bo; \
-        /* phase 0 */                                                                                   \
-        SPHIP_READ_X(xlo, H_XLO);                                                                       \
-        SPHIP_READ_W(H_WLO);                                                                            \
-        if (NEXT) stage(H_XLO, t + 1);                                                                  \
-        WAIT_A; /* retire X-hi(t)              [X-hi(t) W-hi(t) X-lo(t+1)] */                           \
-        seg_barrier();                                                                                  \
-        SPHIP_LGKM0_X(xlo);                                                                             \
-        SPHIP_LGKM0_W();                                                                                \
-        mma(0, 0, xlo);                                                                                 \
-        seg_barrier();                                                                                  \
-        /* phase 1 */                                                                                   \
-        SPHIP_READ_X(xhi, H_XHI);                                                                       \
-        if (NEXT) stage(H_WLO, t + 1);                                                                  \
-        WAIT_B; /* retire W-hi(t)              [W-hi(t) X-lo(t+1) W-lo(t+1)] */                         \
-        seg_barrier();                                                                                  \
-        SPHIP_LGKM0_X(xhi);                                                                             \
-        mma(0, 2, xhi);                                                                                 \
-        seg_barrier();                                                                                  \
-        /* phase 2 */                                                                                   \
-        SPHIP_READ_W(H_WHI);                                                                            \
-        if (NEXT) stage(H_XHI, t + 1);                                                                  \
-        seg_barrier();                                                                                  \
-        SPHIP_LGKM0_W();                                                                                \
-        mma(4, 2, xhi);                                                                                 \
-        seg_barrier();                                                                                  \
-        /* phase 3 */                                                                                   \
-        if (NEXT) stage(H_WHI, t + 1);                                                                  \
-        WAIT_C; /* retire X-lo(t+1), W-lo(t+1) [X-lo W-lo X-hi W-hi (t+1)] */                           \
-        seg_barrier();                                                                                  \
-        mma(4, 0, xlo);                                                                                 \
-        seg_barrier();                                                                                  \
+    // One K tile. Outstanding DMA per wave, in issue order, at the two waits:
+    //   L0: [W-hi(t) 2][X(t+1) 4][W-lo(t+1) 2]      L1: [X(t+1) 4][W-lo(t+1) 2][W-hi(t+1) 2]
+#define SPHIP_KTILE(ISSUE_HI, ISSUE_X, WAIT_L0, WAIT_L1)                                         \
+    {                                                                                           \
+        const unsigned bo = (unsigned)(t & 1) * BUF_BYTES;                                      \
+        /* L0 */                                                                                \
+        if (!(DIAG & 4)) {                                                                      \
+            { const unsigned a0 = xbase[0] + bo, a1 = xbase[1] + bo; SPHIP_READ4(xf, R_X); }    \
+            { const unsigned a0 = wbase[0] + bo, a1 = wbase[1] + bo; SPHIP_READ4(wf, R_WLO); }  \
+        }                                                                                       \
+        WAIT_L0;                                                                                \
+        SPHIP_STAMP(0)                                                                          \
+        seg_barrier();                                                                          \
+        SPHIP_STAMP(1)                                                                          \
+        /* M0 */                                                                                \
+        SPHIP_LGKM0(xf);                                                                        \
+        SPHIP_LGKM0(wf);                                                                        \
+        SPHIP_STAMP(2)                                                                          \
+        mma(0, ((ISSUE_HI) && !(DIAG & 1)) ? 2 : 0, [&](int j) { stage_w1(1, t + 1, j); });       \
+        SPHIP_STAMP(3)                                                                          \
+        SPHIP_STAMP(4)                                                                          \
+        /* L1 */                                                                                \
+        if (!(DIAG & 4)) {                                                                      \
+            const unsigned a0 = wbase[0] + bo, a1 = wbase[1] + bo;                              \
+            SPHIP_READ4(wf, R_WHI);                                                             \
+        }                                                                                       \
+        WAIT_L1;                                                                                \
+        SPHIP_STAMP(5)                                                                          \
+        seg_barrier();                                                                          \
+        SPHIP_STAMP(6)                                                                          \
+        /* M1 */                                                                                \
+        SPHIP_LGKM0(wf);                                                                        \
+        SPHIP_STAMP(7)                                                                          \
+        mma(4, ((ISSUE_X) && !(DIAG & 1)) ? 6 : 0, [&](int j) {                                  \
+            if (j < 4) stage_x1(t + 2, j);                                                      \
+            else stage_w1(0, t + 2, j - 4);                                                     \
+        });                                                                                     \
+        SPHIP_STAMP(8)                                                                          \
+        SPHIP_STAMP(9)                                                                          \
     }
 
     int t = 0;
-    for (; t < kTiles - 1; ++t) SPHIP_KTILE(true, SPHIP_VMCNT(4), SPHIP_VMCNT(4), SPHIP_VMCNT(4))
-    // last K tile: nothing left to stage; outstanding = [X-hi(t) W-hi(t)]
-    SPHIP_KTILE(false, SPHIP_VMCNT(2), SPHIP_VMCNT(0), (void)0)
+    for (; t < kTiles - 2; ++t) SPHIP_KTILE(true, true, SPHIP_VMCNT(6), SPHIP_VMCNT(2))
+    if (kTiles > 1) {
+        SPHIP_KTILE(true, false, SPHIP_VMCNT(6), SPHIP_VMCNT(2))
+        ++t;
+    }
+    SPHIP_KTILE(false, false, SPHIP_VMCNT(0), (void)0)
 #undef SPHIP_KTILE
 
     if (wm == 0) seg_barrier();          // matches the stagger barrier of the other group
+    if ((DIAG & 32) && dbg != nullptr && (blockIdx.x % 4099) == 7 && lane == 0) {
+        unsigned* o = dbg + ((blockIdx.x / 4099) * 8 + wave) * 10;
+        for (int i = 0; i < 10; ++i) o[i] = tacc[i];
+    }
 
-    // ---- epilogue: + bias, relu, one rounding to bf16; lane owns 4 consecutive latents of
-    //      one token per accumulator tile (C/D map of 16x16: col = lane&15, row = 4*(lane>>4)+reg)
-    const bool vec = (M & 3) == 0;
+    // ---- epilogue: + bias, relu, one rounding to bf16. A lane owns 4 consecutive latents of
+    // one token per accumulator tile (C/D map of 16x16: col = lane&15, row = 4*(lane>>4)+reg),
+    // i.e. 8-B pieces; the wave's 64 x 128 sub-tile goes through a private LDS area (the
+    // staging image is dead after the barrier above) and leaves as 256-B row segments.
+    char* epi = smem + wave * EPI_WAVE;
+    float bv[8][4];
+    {
+        const bool bvec = (((uintptr_t)bias & 7) == 0);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[mi][j] = 0.f;
+            if (bias == nullptr) continue;
+            if (bvec && m + 3 < M) {
+                const float4 b4 = load4(bias + m);
+                bv[mi][0] = b4.x, bv[mi][1] = b4.y, bv[mi][2] = b4.z, bv[mi][3] = b4.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m + j < M) bv[mi][j] = bf16_to_f32(bias[m + j]);
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m + j < M) bv[j] = bf16_to_f32(bias[m + j]);
-        }
+        const int ml = (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + (ni >> 1) * 32 + (ni & 1) * 16 + r16;
-            if (n >= N || m >= M) continue;
             bf16_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v = acc[mi][ni][j] + bv[j];
+                const float v = acc[mi][ni][j] + bv[mi][j];
                 o[j] = f32_to_bf16(RELU ? (v > 0.f ? v : 0.f) : v);
             }
-            bf16_t* dst = P + (int64_t)n * M + m;
-            if (vec && m + 3 < M) {
-                *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16),
-                                                            (unsigned)o[2] | ((unsigned)o[3] << 16));
-            } else {
-                for (int j = 0; j < 4 && m + j < M; ++j) dst[j] = o[j];
-            }
+            *reinterpret_cast<uint2*>(epi + (ni * 16 + r16) * EPI_ROW + ml * 2) =
+                make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (DIAG & 8) return;
+    const int chunk = lane & 15;
+    const int mcol = m0 + wm * 128 + chunk * 8;
+    const bool vec = (M & 7) == 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int tok = i * 4 + (lane >> 4);
+        const int n = n0 + wn * 64 + tok;
+        const uint4 v = *reinterpret_cast<const uint4*>(epi + tok * EPI_ROW + chunk * 16);
+        if (n >= N || mcol >= M) continue;
+        bf16_t* dst = P + (int64_t)n * M + mcol;
+        if (vec) {
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 8 && mcol + j < M; ++j) dst[j] = (bf16_t)(w4[j >> 1] >> ((j & 1) * 16));
         }
     }
 }
 
+// Diagnostic builds (make DIAG=1): SPHIP_GEMM_DIAG selects a kernel with parts of the loop
+// removed (bit 0: no DMA, 1: no MFMA, 2: no ds_read, 3: no epilogue store, 4: every tile reads
+// tile 0/1 of each operand, 5: per-segment cycle stamps written to the SPHIP_GEMM_DBG
+// buffer); benchmarks/gemm_bench.py and benchmarks/gemm_stamps.py drive them.
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, int64_t N, int64_t D,
@@ -281,6 +362,38 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         attr_set[relu ? 1 : 0] = true;
     }
     dim3 grid((unsigned)nblocks), block(512);
+#ifdef SPHIP_DIAG
+    const char* dg = getenv("SPHIP_GEMM_DIAG");
+    const int diag = dg ? atoi(dg) : 0;
+    const char* dbs = getenv("SPHIP_GEMM_DBG");
+    unsigned* dbgp = dbs ? (unsigned*)strtoull(dbs, nullptr, 0) : nullptr;
+#define SPHIP_DIAG_LAUNCH(DG)                                                                                     \
+    {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            G_LDS_BYTES);                                                                         \
+        hipLaunchKernelGGL((encoder_gemm256_kernel<true, DG>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,       \
+                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, dbgp); \
+    }
+    if (diag == 1) SPHIP_DIAG_LAUNCH(1)
+    else if (diag == 2) SPHIP_DIAG_LAUNCH(2)
+    else if (diag == 3) SPHIP_DIAG_LAUNCH(3)
+    else if (diag == 4) SPHIP_DIAG_LAUNCH(4)
+    else if (diag == 5) SPHIP_DIAG_LAUNCH(5)
+    else if (diag == 6) SPHIP_DIAG_LAUNCH(6)
+    else if (diag == 7) SPHIP_DIAG_LAUNCH(7)
+    else if (diag == 8) SPHIP_DIAG_LAUNCH(8)
+    else if (diag == 13) SPHIP_DIAG_LAUNCH(13)
+    else if (diag == 15) SPHIP_DIAG_LAUNCH(15)
+    else if (diag == 16) SPHIP_DIAG_LAUNCH(16)
+    else if (diag == 32) SPHIP_DIAG_LAUNCH(32)
+    else if (diag == 33) SPHIP_DIAG_LAUNCH(33)
+    else if (diag == 36) SPHIP_DIAG_LAUNCH(36)
+    else if (diag == 45) SPHIP_DIAG_LAUNCH(45)
+    else if (diag == 37) SPHIP_DIAG_LAUNCH(37)
+    else if (diag == 22) SPHIP_DIAG_LAUNCH(22)
+    else if (diag == 20) SPHIP_DIAG_LAUNCH(20)
+    else
+#endif
     if (relu)
         hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
                            (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN);
