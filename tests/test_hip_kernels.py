@@ -182,6 +182,28 @@ def test_gather_rows_weighted(device, N, k, M, D, cdtype):
     torch.testing.assert_close(got2, ref - bias, rtol=1e-5, atol=1e-5 * k**0.5)
 
 
+@pytest.mark.parametrize("N,k,M,D", [(7, 13, 300, 256), (130, 192, 4096, 1024), (33, 8, 64, 4096)])
+@pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
+def test_gather_sliced_kernel_matches_full(device, monkeypatch, N, k, M, D, cdtype):
+    """The Infinity-Cache-sliced kernel (picked for the training shapes) against the oracle and,
+    bit for bit, against the token-per-workgroup kernel; negative indices are inactive slots."""
+    from sparsify_amd import ops
+    torch.manual_seed(N)
+    table = torch.randn(M, D)
+    idx = torch.randint(0, M, (N, k))
+    idx[::3, ::4] = -1
+    coeff = torch.randn(N, k).to(cdtype)
+    bias = torch.randn(D)
+    outs = {}
+    for mode in ("full", "sliced"):
+        monkeypatch.setenv("SPHIP_GATHER", mode)
+        outs[mode] = ops.gather_rows_weighted(dev(idx), dev(coeff), dev(table), dev(bias)).cpu()
+    assert torch.equal(outs["full"], outs["sliced"])
+    live = (idx >= 0)
+    ref = O.gather_sum(idx.clamp(min=0), coeff.float() * live, table) + bias
+    torch.testing.assert_close(outs["sliced"], ref, rtol=1e-5, atol=1e-5 * k**0.5)
+
+
 # ------------------------------------------------------------------ segments
 @pytest.mark.parametrize("N,k,M", [(2, 10, 128), (96, 24, 640), (1000, 32, 24576), (300, 192, 131072),
                                     (17, 5, 7), (64, 16, 1 << 20), (4096, 32, 2049)])
