@@ -104,7 +104,9 @@ int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_
  *   it: gW[j,:] = sum c*rows - (sum c)*row_shift).
  * coeff (N,k) of coeff_dtype, rows (N,D) of rows_dtype, W (M,D) fp32, outputs fp32.
  * Sums run in segment order, so results are bitwise reproducible.
- * workspace (sphip_weight_grad_workspace_bytes): the segment-ordered (entry, coeff) list. */
+ * workspace (sphip_weight_grad_workspace_bytes): the segment-ordered (entry, coeff) list plus
+ *   either a slice-major copy of rows (no dcoeff) or the per-column-slice partial dots of
+ *   dcoeff (D/256 floats per entry), whichever is larger. */
 size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
 int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                 int coeff_dtype, const void* rows, int rows_dtype, const float* W,

@@ -236,6 +236,111 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     if (gbias != nullptr && slice == 0 && sub == 0 && j < M) gbias[j] = bsum;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Wide-sliced variant WITH dcoeff (the W_dec gradient of the training shapes): one wave per
+// (latent, 256-column slice), slices are the slow grid dimension, so the whole chip reduces
+// the same N x 1 KiB column slice of `rows` (16 MiB at N = 16384) at a time and its k-fold
+// re-reads are served by the Infinity Cache / L2 instead of HBM. A lane owns 4 columns.
+// The dot product is split by slice: the 8 entries of a batch leave 8 partial products per
+// lane, a 10-step transposing butterfly leaves the slice's dot of entry u in lanes 8u..8u+7,
+// and lanes 0, 8, .., 56 store 8 consecutive floats of the slab[slice][position] array;
+// seg_dcoeff_kernel then sums the slices in a fixed order. Entry metadata is wave-uniform
+// (scalar loads). gW is summed in segment order: bitwise the same as the full-row kernel.
+template <typename RT>
+__global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __restrict__ packed,
+                                                             const int* __restrict__ seg_begin,
+                                                             const RT* __restrict__ rows,
+                                                             const float* __restrict__ W, float* __restrict__ gW,
+                                                             float* __restrict__ gbias, float* __restrict__ slab,
+                                                             const float* __restrict__ row_shift, FastDiv kdiv,
+                                                             int64_t E, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (j >= M) return;
+    const int slice = blockIdx.y;
+    const int col = slice * 256 + lane * 4;
+    const int beg = seg_begin[j], end = seg_begin[j + 1];
+    const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)j * D + col);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    const RT* rcol = rows + col;
+    float* sl = slab + (int64_t)slice * E;
+
+    constexpr int U = 8;
+    for (int p = beg; p < end; p += U) {
+        float c[U];
+        float4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < end) {                       // wave-uniform
+                const uint2 pk = packed[p + u];
+                c[u] = __uint_as_float(pk.y);
+                r[u] = load4(rcol + (int64_t)fastdiv(pk.x, kdiv) * D);
+            } else {
+                c[u] = 0.f;
+                r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < end) {                       // keeps the sequential fma chain exact
+                acc.x = fmaf(c[u], r[u].x, acc.x);
+                acc.y = fmaf(c[u], r[u].y, acc.y);
+                acc.z = fmaf(c[u], r[u].z, acc.z);
+                acc.w = fmaf(c[u], r[u].w, acc.w);
+                bsum += c[u];
+            }
+            d[u] = fmaf(r[u].w, w.w, fmaf(r[u].z, w.z, fmaf(r[u].y, w.y, r[u].x * w.x)));
+        }
+        // transposing butterfly: 8 values x 64 lanes -> lane l holds the wave sum of d[l >> 3]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool up = lane & 32;
+            const float keep = up ? d[t + 4] : d[t], send = up ? d[t] : d[t + 4];
+            d[t] = keep + __shfl_xor(send, 32, 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool up = lane & 16;
+            const float keep = up ? d[t + 2] : d[t], send = up ? d[t] : d[t + 2];
+            d[t] = keep + __shfl_xor(send, 16, 64);
+        }
+        {
+            const bool up = lane & 8;
+            const float keep = up ? d[1] : d[0], send = up ? d[0] : d[1];
+            d[0] = keep + __shfl_xor(send, 8, 64);
+        }
+        d[0] += __shfl_xor(d[0], 4, 64);
+        d[0] += __shfl_xor(d[0], 2, 64);
+        d[0] += __shfl_xor(d[0], 1, 64);
+        const int u = lane >> 3;
+        if ((lane & 7) == 0 && p + u < end) sl[p + u] = d[0];
+    }
+    if (row_shift != nullptr) {
+        const float4 sh = *reinterpret_cast<const float4*>(row_shift + col);
+        acc.x = fmaf(-bsum, sh.x, acc.x);
+        acc.y = fmaf(-bsum, sh.y, acc.y);
+        acc.z = fmaf(-bsum, sh.z, acc.z);
+        acc.w = fmaf(-bsum, sh.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
+    if (gbias != nullptr && slice == 0 && lane == 0) gbias[j] = bsum;
+}
+
+// dcoeff[entry at position p] = sum over slices of slab[slice][p], slices in ascending order
+__global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __restrict__ packed,
+                                                                 const float* __restrict__ slab, int64_t E,
+                                                                 const int* __restrict__ seg_begin, int M,
+                                                                 int num_slices, float* __restrict__ dcoeff) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= seg_begin[M]) return;
+    float t = 0.f;
+    for (int sidx = 0; sidx < num_slices; ++sidx) t += slab[(int64_t)sidx * E + p];
+    dcoeff[packed[p].x] = t;
+}
+
 template <typename RT>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s) {
@@ -275,11 +380,18 @@ static void launch_nv(const uint2* packed, const int* seg, const void* rows, con
 }  // namespace sphip
 
 static size_t packed_bytes(int64_t N, int64_t k) { return (((size_t)N * (size_t)k * sizeof(uint2)) + 255) & ~(size_t)255; }
+static size_t rows_sm_bytes(int64_t N, int64_t D) { return (size_t)N * (size_t)(((D * 4 + 127) / 128) * 128); }
+// the wide-sliced dcoeff path: D a multiple of 256 with at least two slices
+static bool wide_eligible(int64_t D) { return D % 256 == 0 && D >= 512 && D / 256 <= 65535; }
+static size_t slab_bytes(int64_t N, int64_t k, int64_t D) {
+    return wide_eligible(D) ? (size_t)(D / 256) * (size_t)N * (size_t)k * sizeof(float) : 0;
+}
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
     if (N <= 0 || k <= 0 || D <= 0) return 0;
-    // packed entry list + slice-major copy of `rows` (<= N * roundup(D*4, 128) bytes)
-    return packed_bytes(N, k) + (size_t)N * (size_t)(((D * 4 + 127) / 128) * 128);
+    // packed entry list + max(slice-major copy of `rows` (no dcoeff), per-slice dot slab (dcoeff))
+    const size_t a = rows_sm_bytes(N, D), b = slab_bytes(N, k, D);
+    return packed_bytes(N, k) + (a > b ? a : b);
 }
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
@@ -320,6 +432,22 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
         }
+    }
+    if (dot && wide_eligible(D) && !(force && force[0] == 'f') &&
+        ((force && force[0] == 's') || (N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20) && N * k >= 4 * M))) {
+        float* slab = (float*)rows_sm;
+        const FastDiv kd = make_fastdiv((unsigned)k);
+        dim3 grid((unsigned)cdiv(M, 4), (unsigned)(D / 256)), block(256);
+        if (rows_dtype == SPHIP_F32)
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+        else
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+        SPHIP_CHECK_LAUNCH("segmented_weight_grad(wide)");
+        // positions >= seg_begin[M] belong to inactive slots (zeroed by seg_pack_kernel); the
+        // device-side bound is read by the kernel, the grid covers all E positions
+        hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 256), dcoeff);
+        SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
+        return SPHIP_OK;
     }
     if (rows_dtype == SPHIP_F32) {
         if (dot) launch_nv<float, true>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
