@@ -160,9 +160,12 @@ int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16
                        void* stream);
 
 /* trainer.py:513-518 fused for one decoder matrix: projected gradient (not written back)
- * followed by the SignSGD step on W, one pass over (W, G). */
+ * followed by the SignSGD step on W, one pass over (W, G). renorm != 0 additionally applies
+ * set_decoder_norm_to_unit_norm (sparse_coder.py:273-279) to the updated rows in the same
+ * pass -- the normalisation that opens the next train step (trainer.py:408); the result is
+ * bitwise that of the step followed by sphip_unit_norm_rows. */
 int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr,
-                                  void* stream);
+                                  int renorm, void* stream);
 
 /* ---------------------------------------------------------------- dead-latent bookkeeping */
 

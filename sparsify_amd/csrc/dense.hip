@@ -113,6 +113,78 @@ __global__ __launch_bounds__(256) void decoder_row_kernel(float* __restrict__ W,
     }
 }
 
+
+// Row-resident forms (D <= 1024 * R, D % 4 == 0): the row (and its gradient) is loaded once
+// into registers, R float4 per thread, so every operand crosses HBM exactly once.
+// OP 0: W /= ||W|| + eps.   OP 1: W -= lr * sign(G - <G,W> W).   OP 2: OP 1 then OP 0 on the
+// updated row (optimizer step + the re-normalisation that opens the next train step,
+// trainer.py:408). The reductions add in the same order as the two-sweep kernels above, so
+// results are bitwise identical to them.
+template <int R, int OP>
+__global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __restrict__ W, const float* __restrict__ G,
+                                                                   int D, float lr, float eps) {
+    __shared__ float red[16];
+    float* w = W + (int64_t)blockIdx.x * D;
+    const float* g = G + (int64_t)blockIdx.x * D;
+    float4 b[R], a[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 4;
+        b[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (OP != 0) a[i] = c < D ? *reinterpret_cast<const float4*>(g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (OP != 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            acc = fmaf(a[i].x, b[i].x, acc); acc = fmaf(a[i].y, b[i].y, acc);
+            acc = fmaf(a[i].z, b[i].z, acc); acc = fmaf(a[i].w, b[i].w, acc);
+        }
+        const float par = block_sum(acc, red);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float4 p = make_float4(a[i].x - par * b[i].x, a[i].y - par * b[i].y, a[i].z - par * b[i].z,
+                                         a[i].w - par * b[i].w);
+            b[i].x -= lr * (float)((p.x > 0.f) - (p.x < 0.f));
+            b[i].y -= lr * (float)((p.y > 0.f) - (p.y < 0.f));
+            b[i].z -= lr * (float)((p.z > 0.f) - (p.z < 0.f));
+            b[i].w -= lr * (float)((p.w > 0.f) - (p.w < 0.f));
+        }
+    }
+    if (OP != 1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int c = (threadIdx.x + 256 * i) * 4;
+            if (c < D) {
+                acc = fmaf(b[i].x, b[i].x, acc); acc = fmaf(b[i].y, b[i].y, acc);
+                acc = fmaf(b[i].z, b[i].z, acc); acc = fmaf(b[i].w, b[i].w, acc);
+            }
+        }
+        const float denom = sqrtf(block_sum(acc, red)) + eps;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            b[i].x /= denom; b[i].y /= denom; b[i].z /= denom; b[i].w /= denom;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 4;
+        if (c < D) *reinterpret_cast<float4*>(w + c) = b[i];
+    }
+}
+
+template <int OP>
+static bool launch_row_resident(float* W, const float* G, int64_t M, int64_t D, float lr, float eps, hipStream_t s) {
+    if (D % 4 != 0 || D > 8192 || ((uintptr_t)W & 15) != 0 || ((uintptr_t)G & 15) != 0) return false;
+    dim3 grid((unsigned)M), block(256);
+    if (D <= 1024) hipLaunchKernelGGL((decoder_row_resident_kernel<1, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
+    else if (D <= 2048) hipLaunchKernelGGL((decoder_row_resident_kernel<2, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
+    else if (D <= 4096) hipLaunchKernelGGL((decoder_row_resident_kernel<4, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
+    else hipLaunchKernelGGL((decoder_row_resident_kernel<8, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void signsgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
                                                       float lr, bf16_t* __restrict__ shadow) {
     const int64_t n4 = n >> 2;
@@ -210,12 +282,18 @@ extern "C" int sphip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vo
     return SPHIP_OK;
 }
 
+static const float SPHIP_F32_EPS = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
+
 extern "C" int sphip_unit_norm_rows(float* W, int64_t M, int64_t D, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W, SPHIP_EINVAL, "unit_norm_rows: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "unit_norm_rows: bad shape");
-    const float eps = 1.1920928955078125e-07f;   // torch.finfo(torch.float32).eps
+    const float eps = SPHIP_F32_EPS;
     hipStream_t s = (hipStream_t)stream;
+    if (launch_row_resident<0>(W, W, M, D, 0.f, eps, s)) {
+        SPHIP_CHECK_LAUNCH("unit_norm_rows");
+        return SPHIP_OK;
+    }
     if (D % 4 == 0 && ((uintptr_t)W & 15) == 0) hipLaunchKernelGGL((unit_norm_kernel<4>), dim3((unsigned)M), dim3(256), 0, s, W, (int)D, eps);
     else hipLaunchKernelGGL((unit_norm_kernel<1>), dim3((unsigned)M), dim3(256), 0, s, W, (int)D, eps);
     SPHIP_CHECK_LAUNCH("unit_norm_rows");
@@ -244,8 +322,21 @@ extern "C" int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, i
     return decoder_row_op(const_cast<float*>(W), G, M, D, 0.f, 0, stream, "remove_parallel_grad");
 }
 
-extern "C" int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr, void* stream) {
-    return decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
+extern "C" int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr, int renorm,
+                                             void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && G, SPHIP_EINVAL, "decoder_project_signsgd: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "decoder_project_signsgd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const bool done = renorm ? launch_row_resident<2>(W, G, M, D, lr, SPHIP_F32_EPS, s)
+                             : launch_row_resident<1>(W, G, M, D, lr, SPHIP_F32_EPS, s);
+    if (done) {
+        SPHIP_CHECK_LAUNCH("decoder_project_signsgd");
+        return SPHIP_OK;
+    }
+    const int st = decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
+    if (st != SPHIP_OK || !renorm) return st;
+    return sphip_unit_norm_rows(W, M, D, stream);
 }
 
 extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow, void* stream) {

@@ -352,11 +352,12 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
     return p
 
 
-def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float) -> Tensor:
+def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = False) -> Tensor:
+    """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows."""
     _req(W, "W_dec", torch.float32, 2)
     _req(G, "W_dec.grad", torch.float32, 2)
     check(_lib.load().sphip_decoder_project_signsgd(W.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1], float(lr),
-                                                   _stream(W)), "sphip_decoder_project_signsgd")
+                                                   int(renorm), _stream(W)), "sphip_decoder_project_signsgd")
     return W
 
 

@@ -17,6 +17,9 @@ class SignSGD(Optimizer):
         if lr <= 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
         super().__init__(params, {"lr": lr})
+        # ids of "renorm_rows" parameters whose rows were left unit-norm by the last step();
+        # the trainer consumes an id instead of normalising that decoder again
+        self.renormalised: set[int] = set()
 
     @torch.no_grad()
     def step(self, closure: None = None) -> None:
@@ -24,15 +27,20 @@ class SignSGD(Optimizer):
         for group in self.param_groups:
             lr = group["lr"]
             project = group.get("project_rows", False)
+            renorm = group.get("renorm_rows", False)
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if project:
                     # decoder matrix: remove_gradient_parallel_to_decoder_directions
-                    # (sparse_coder.py:281-295) fused with the sign step, one pass over (W, G)
-                    ops.decoder_project_signsgd_(p.data, g, lr)
+                    # (sparse_coder.py:281-295) fused with the sign step, one pass over (W, G);
+                    # "renorm_rows" also applies the set_decoder_norm_to_unit_norm that opens
+                    # the next train step (trainer.py:408) while the rows are in registers
+                    ops.decoder_project_signsgd_(p.data, g, lr, renorm)
                     torch.autograd.graph.increment_version(p)
+                    if renorm:
+                        self.renormalised.add(id(p))
                     continue
                 shadow = peek_bf16_shadow(p)
                 ops.signsgd_step_(p.data, g, lr, shadow)

@@ -163,7 +163,7 @@ class Trainer:
                     dec = [sae.W_dec] if (project and sae.W_dec is not None) else []
                     rest = [p for p in sae.parameters() if not any(p is d for d in dec)]
                     if dec:
-                        pgs.append(dict(params=dec, lr=lr, project_rows=True))
+                        pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
                 self.optimizers = [SignSGD(pgs)]
                 self._fused_projection = project
@@ -247,7 +247,13 @@ class Trainer:
             raw.b_dec.data = mean.to(raw.dtype)
 
         if raw.cfg.normalize_decoder and not cfg.sae.transcode:
-            raw.set_decoder_norm_to_unit_norm()
+            # trainer.py:408. The fused SignSGD step already left the rows unit-norm (same
+            # arithmetic, done while the updated rows were in registers): consume that once.
+            done = getattr(self.optimizers[0], "renormalised", None)
+            if done is not None and id(raw.W_dec) in done:
+                done.discard(id(raw.W_dec))
+            else:
+                raw.set_decoder_norm_to_unit_norm()
 
         dead_mask = None
         if cfg.auxk_alpha > 0:

@@ -326,6 +326,31 @@ def test_dense_updates_vs_reference_golden(device):
     assert (g["G1"][bad].abs() < 1e-5).all()
 
 
+@pytest.mark.parametrize("M,D", [(64, 48), (100, 1024), (37, 1028), (50, 4096), (9, 8192), (5, 8196), (3, 16384)])
+def test_decoder_row_kernels_fused_vs_separate(device, M, D):
+    """unit-norm / projected sign step / both fused: the row-resident kernels (D <= 8192) and the
+    two-sweep fallbacks must agree bit for bit with the separate reference steps."""
+    from sparsify_amd import ops
+    torch.manual_seed(M + D)
+    W0 = torch.randn(M, D)
+    G = torch.randn(M, D)
+    W1 = dev(W0.clone())
+    ops.unit_norm_rows_(W1)
+    torch.testing.assert_close(W1.cpu(), O.unit_norm_rows(W0), rtol=2e-6, atol=1e-7)
+    # separate: project+sign, then normalise
+    Wa = W1.clone()
+    ops.decoder_project_signsgd_(Wa, dev(G), 3e-3)
+    ref = O.signsgd_update(W1.cpu(), O.remove_parallel_component(G, W1.cpu()), 3e-3)
+    bad = (Wa.cpu() - ref).abs() > 1e-7          # sign() of a ~0 projected component may flip
+    assert bad.float().mean() < 2e-3
+    ops.unit_norm_rows_(Wa)
+    # fused
+    Wb = W1.clone()
+    ops.decoder_project_signsgd_(Wb, dev(G), 3e-3, renorm=True)
+    assert torch.equal(Wa, Wb)
+    torch.testing.assert_close(Wb.cpu().norm(dim=1), torch.ones(M), rtol=1e-5, atol=0)
+
+
 def test_dead_latent_bookkeeping(device):
     from sparsify_amd import ops
     M = 1000
