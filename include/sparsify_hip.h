@@ -53,17 +53,30 @@ int sphip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream)
 /* FusedEncoder.forward, fused_encoder.py:29: pre = relu(x W^T + b).
  * x (N,D), W (M,D), bias (M) or NULL, pre (N,M); all of `dtype` (bf16: MFMA bf16 with fp32
  * accumulate, one rounding to bf16 in the epilogue; f32: exact-fp32 MFMA). relu = 0 keeps
- * the raw affine output. Requires D % 8 == 0 (bf16) / D % 4 == 0 (f32). */
-int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, int dtype,
-                          int64_t N, int64_t D, int64_t M, int relu, void* stream);
+ * the raw affine output. Requires D % 8 == 0 (bf16) / D % 4 == 0 (f32).
+ * tile_max, or NULL: the maximum of pre over each block of SPHIP_TOPK_TILE consecutive
+ * latents (taken in the GEMM epilogue for the large bf16 shapes, by a small extra kernel
+ * otherwise); sphip_topk uses it to skip the blocks of a row that cannot hold a selected
+ * latent. ceil(N/64) * T * 64 elements of `dtype`, T = ceil(M / SPHIP_TOPK_TILE); the
+ * maximum of block t of token n is element ((n / 64) * T + t) * 64 + n % 64 (64 tokens of
+ * one block are contiguous: the GEMM writes whole 128-byte lines). */
+#define SPHIP_TOPK_TILE 128
+int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre,
+                          void* tile_max, int dtype, int64_t N, int64_t D, int64_t M, int relu,
+                          void* stream);
 
 /* torch.topk(pre, k, dim=-1, sorted=False), fused_encoder.py:33 -- and, with keep_mask,
  * torch.where(dead_mask[None], pre, -inf).topk(k_aux), sparse_coder.py:240-243.
  * pre (N,M) of `dtype`; keep_mask (M) uint8 or NULL; vals (N,k) of `dtype`; idx (N,k) int64.
- * Output order: value descending, ties by ascending index (deterministic).
- * Masked-out latents rank as -inf and are selected only if fewer than k are kept. */
-int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, int64_t N, int64_t M,
-               int64_t k, void* vals, int64_t* idx, void* stream);
+ * The selected SET is deterministic (ties go to the lowest index); the order inside a row is
+ * unspecified like sorted=False (value-descending on the usual path, index order on the
+ * exact-bisection path taken for k > 1024 or rows dominated by ties).
+ * Masked-out latents rank as -inf and are selected only if fewer than k are kept.
+ * tile_max: the block maxima written by sphip_encoder_preacts for this `pre` (same layout),
+ * or NULL. When given (and keep_mask is NULL) only the blocks whose maximum
+ * reaches the k-th largest block maximum are read; the result is identical either way. */
+int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max,
+               int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx, void* stream);
 
 /* groupmax, fused_encoder.py:34-43: max over k contiguous groups of M/k latents. M % k == 0. */
 int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, void* vals,

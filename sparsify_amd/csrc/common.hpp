@@ -86,6 +86,34 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
     return r;
 }
 
+// Order-preserving unsigned image of a value's bits (16 bit for bf16, 32 bit for f32): the
+// selection kernels compare keys; key 0 is reserved for "masked out" (-inf on the way back).
+__device__ __forceinline__ unsigned to_key(bf16_t u) {
+    const unsigned v = u;
+    return (v & 0x8000u) ? ((~v) & 0xffffu) : (v | 0x8000u);
+}
+__device__ __forceinline__ unsigned to_key(float f) {
+    const unsigned v = __float_as_uint(f);
+    return (v & 0x80000000u) ? ~v : (v | 0x80000000u);
+}
+template <typename T> struct KeyOf;
+template <> struct KeyOf<bf16_t> {
+    static constexpr int BITS = 16;
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ bf16_t value(unsigned key) {
+        if (key == 0) return (bf16_t)0xff80u;   // masked-out latent -> -inf
+        return (bf16_t)((key & 0x8000u) ? (key & 0x7fffu) : ((~key) & 0xffffu));
+    }
+};
+template <> struct KeyOf<float> {
+    static constexpr int BITS = 32;
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ float value(unsigned key) {
+        if (key == 0) return __uint_as_float(0xff800000u);
+        return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -203,13 +203,42 @@ static int launch_gemm(const void* x, const void* W, const void* bias, void* pre
     return SPHIP_OK;
 }
 
-bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, int64_t N, int64_t D,
-                         int64_t M, int relu, hipStream_t s, int* status);   // encoder_gemm256.hip
+bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
+                         int64_t D, int64_t M, int relu, hipStream_t s, int* status);   // encoder_gemm256.hip
+
+// Block maxima of pre for the kernels that do not take them in their epilogue (small shapes,
+// fp32): one wave per (token, 128-latent block). NaNs rank above +inf, as in topk.hip.
+template <typename T>
+__global__ __launch_bounds__(256) void tile_max_kernel(const T* __restrict__ pre, T* __restrict__ tile_max,
+                                                       int64_t total, int M, int tilesT) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= total) return;
+    const int64_t n = gid / tilesT;
+    const int t = (int)(gid % tilesT);
+    const T* p = pre + n * M + (int64_t)t * 128;
+    unsigned kmax = 0;
+    for (int i = lane; i < 128 && t * 128 + i < M; i += 64) kmax = max(kmax, to_key(p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
+    if (lane == 0) tile_max[((n >> 6) * tilesT + t) * 64 + (n & 63)] = KeyOf<T>::value(kmax);
+}
+
+template <typename T>
+static int launch_tile_max(const void* pre, void* tile_max, int64_t N, int64_t M, hipStream_t s) {
+    const int tilesT = (int)cdiv(M, 128);
+    const int64_t total = N * tilesT;
+    SPHIP_REQUIRE(cdiv(total, 4) < (1ll << 31), SPHIP_EUNSUPPORTED, "encoder_preacts: tile_max grid too large");
+    hipLaunchKernelGGL((tile_max_kernel<T>), dim3((unsigned)cdiv(total, 4)), dim3(256), 0, s, (const T*)pre,
+                       (T*)tile_max, total, (int)M, tilesT);
+    SPHIP_CHECK_LAUNCH("encoder_preacts(tile_max)");
+    return SPHIP_OK;
+}
 
 }  // namespace sphip
 
-extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, int dtype,
-                                     int64_t N, int64_t D, int64_t M, int relu, void* stream) {
+extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, void* tile_max,
+                                     int dtype, int64_t N, int64_t D, int64_t M, int relu, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "encoder_preacts: bad dtype %d", dtype);
     SPHIP_REQUIRE(x && W && pre, SPHIP_EINVAL, "encoder_preacts: null pointer");
@@ -229,8 +258,12 @@ extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* b
         const char* force = getenv("SPHIP_GEMM");
         const bool want256 = force ? (force[0] == '2') : (cdiv(M, 256) * cdiv(N, 256) >= 256);
         int status = SPHIP_OK;
-        if (want256 && launch_gemm256_bf16(x, W, bias, pre, N, D, M, relu, s, &status)) return status;
-        return launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
+        if (want256 && launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M, relu, s, &status)) return status;
+        status = launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
+        if (status != SPHIP_OK || tile_max == nullptr) return status;
+        return launch_tile_max<bf16_t>(pre, tile_max, N, M, s);
     }
-    return launch_gemm<float>(x, W, bias, pre, N, D, M, relu, s);
+    const int status = launch_gemm<float>(x, W, bias, pre, N, D, M, relu, s);
+    if (status != SPHIP_OK || tile_max == nullptr) return status;
+    return launch_tile_max<float>(pre, tile_max, N, M, s);
 }

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ W,
                                                                  const bf16_t* __restrict__ bias,
                                                                  bf16_t* __restrict__ P, int N, int D, int M,
-                                                                 int tilesM, int tilesN, unsigned* dbg = nullptr) {
+                                                                 int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
+                                                                 unsigned* dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
@@ -324,11 +325,41 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
     const int chunk = lane & 15;
     const int mcol = m0 + wm * 128 + chunk * 8;
     const bool vec = (M & 7) == 0;
+    const int tilesT = (M + 127) >> 7;                  // row length of tile_max
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int tok = i * 4 + (lane >> 4);
         const int n = n0 + wn * 64 + tok;
         const uint4 v = *reinterpret_cast<const uint4*>(epi + tok * EPI_ROW + chunk * 16);
+        if (tile_max != nullptr) {
+            // maximum of the token's 128 latents held by these 16 lanes, in the order-preserving
+            // key domain of the top-k kernel (common.hpp)
+            unsigned kmax;
+            if (RELU) {
+                // relu output is >= +0 (or NaN): the raw bf16 bits already order like the keys,
+                // and the zeros staged for columns past M cannot raise a maximum
+                typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+                const u16x2_t a = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, v.x), __builtin_bit_cast(u16x2_t, v.y));
+                const u16x2_t b2 = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, v.z), __builtin_bit_cast(u16x2_t, v.w));
+                const u16x2_t c2 = __builtin_elementwise_max(a, b2);
+                kmax = max((unsigned)c2.x, (unsigned)c2.y) | 0x8000u;
+            } else {
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+                kmax = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned key = to_key((bf16_t)(w4[j >> 1] >> ((j & 1) * 16)));
+                    kmax = max(kmax, (mcol + j < M) ? key : 0u);
+                }
+            }
+            // 16-lane maximum with DPP row operations (xor 1, xor 2, half mirror, mirror)
+            kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0xB1, 0xF, 0xF, true));
+            kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x4E, 0xF, 0xF, true));
+            kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x141, 0xF, 0xF, true));
+            kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x140, 0xF, 0xF, true));
+            if (chunk == 0 && n < N && m0 + wm * 128 < M)
+                tile_max[((int64_t)(n >> 6) * tilesT + ((m0 + wm * 128) >> 7)) * 64 + (n & 63)] = KeyOf<bf16_t>::value(kmax);
+        }
         if (n >= N || mcol >= M) continue;
         bf16_t* dst = P + (int64_t)n * M + mcol;
         if (vec) {
@@ -346,8 +377,8 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 // buffer); benchmarks/gemm_bench.py and benchmarks/gemm_stamps.py drive them.
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
-bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, int64_t N, int64_t D,
-                         int64_t M, int relu, hipStream_t s, int* status) {
+bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
+                         int64_t D, int64_t M, int relu, hipStream_t s, int* status) {
     if (D % G_BK != 0 || D < G_BK) return false;
     const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
     const int64_t nblocks = (int64_t)tilesM * tilesN;
@@ -372,7 +403,7 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         (void)hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             G_LDS_BYTES);                                                                         \
         hipLaunchKernelGGL((encoder_gemm256_kernel<true, DG>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,       \
-                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, dbgp); \
+                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, dbgp); \
     }
     if (diag == 1) SPHIP_DIAG_LAUNCH(1)
     else if (diag == 2) SPHIP_DIAG_LAUNCH(2)
@@ -396,10 +427,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
 #endif
     if (relu)
         hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max);
     else
         hipLaunchKernelGGL((encoder_gemm256_kernel<false>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("encoder_preacts(256): launch failed: %s", hipGetErrorString(e));

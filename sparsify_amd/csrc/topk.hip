@@ -11,6 +11,11 @@
 //              L2 / Infinity Cache) appends every element >= tau to an LDS candidate list
 //              (wave-aggregated LDS atomic), typically ~1.1 k entries. A bitonic sort of the
 //              candidates on (key desc, index asc) yields the exact, deterministic top-k.
+//   tile path  (block maxima from the GEMM epilogue, no mask): the thread maxima are taken
+//              over the row's block maxima (N x M/128 values, 1/128 of the row) instead of
+//              over the row, and sweep 2 reads only the blocks whose maximum reaches tau --
+//              about k of the M/128 blocks -- 16 lanes per 256-B block. Same tau rule, same
+//              candidate list, same result.
 //   exact path (k > 1024, or more than CAP candidates, e.g. rows full of ties): bisection
 //              of the k-th largest key over the whole row, then an index-ordered emission
 //              (block scans) that takes ties in ascending index order.
@@ -22,32 +27,8 @@ namespace sphip {
 constexpr int TK_THREADS = 1024;
 constexpr int TK_WAVES = TK_THREADS / 64;
 constexpr int TK_CAP = 4096;   // candidate capacity (8 B each -> 32 KB LDS)
-
-__device__ __forceinline__ unsigned to_key(bf16_t u) {
-    const unsigned v = u;
-    return (v & 0x8000u) ? ((~v) & 0xffffu) : (v | 0x8000u);
-}
-__device__ __forceinline__ unsigned to_key(float f) {
-    const unsigned v = __float_as_uint(f);
-    return (v & 0x80000000u) ? ~v : (v | 0x80000000u);
-}
-template <typename T> struct KeyOf;
-template <> struct KeyOf<bf16_t> {
-    static constexpr int BITS = 16;
-    static constexpr int VEC = 8;
-    static __device__ __forceinline__ bf16_t value(unsigned key) {
-        if (key == 0) return (bf16_t)0xff80u;   // masked-out latent -> -inf
-        return (bf16_t)((key & 0x8000u) ? (key & 0x7fffu) : ((~key) & 0xffffu));
-    }
-};
-template <> struct KeyOf<float> {
-    static constexpr int BITS = 32;
-    static constexpr int VEC = 4;
-    static __device__ __forceinline__ float value(unsigned key) {
-        if (key == 0) return __uint_as_float(0xff800000u);
-        return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
-    }
-};
+constexpr int TK_TILE = SPHIP_TOPK_TILE;   // latents per block maximum (sphip_encoder_preacts)
+constexpr int TK_TCAP = 2048;  // selected-block list capacity
 
 // Loads VEC consecutive keys starting at element i (i % VEC == 0 when ALIGNED).
 template <typename T, bool ALIGNED>
@@ -88,15 +69,17 @@ __device__ __forceinline__ unsigned block_count(unsigned c, unsigned* part, int 
 
 template <typename T, bool ALIGNED>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ pre,
-                                                          const uint8_t* __restrict__ keep, int M,
+                                                          const uint8_t* __restrict__ keep,
+                                                          const T* __restrict__ tile_max, int M,
                                                           int k, T* __restrict__ vals,
                                                           int64_t* __restrict__ idx_out) {
     constexpr int V = KeyOf<T>::VEC;
     constexpr int BITS = KeyOf<T>::BITS;
     __shared__ unsigned long long cand[TK_CAP];
     __shared__ unsigned part[2 * TK_WAVES];
-    __shared__ unsigned s_count;
+    __shared__ unsigned s_count, s_ntiles;
     __shared__ unsigned scan_tot[TK_WAVES];
+    __shared__ unsigned short tiles[TK_TCAP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* row = pre + (int64_t)blockIdx.x * M;
@@ -107,13 +90,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ 
 
     bool exact = k > TK_THREADS;
     if (!exact) {
-        // ---- sweep 1: thread maxima
+        const int T_ = (M + TK_TILE - 1) / TK_TILE;
+        // (fewer blocks than k: their maxima bound nothing, take the plain sweep)
+        const bool by_tile = ALIGNED && tile_max != nullptr && keep == nullptr && T_ <= 65536 && T_ >= k;
+        // block maxima of this token: element t at tm_row[t * 64] (layout: sparsify_hip.h)
+        const T* tm_row = tile_max + (int64_t)(blockIdx.x >> 6) * T_ * 64 + (blockIdx.x & 63);
+        // ---- sweep 1: thread maxima (over the block maxima when they are given)
         unsigned tmax = 0;
-        for (int i = tid * V; i < M; i += span) {
-            unsigned key[V];
-            load_keys<T, ALIGNED>(row, keep, i, M, key);
+        if (by_tile) {
+            for (int t = tid; t < T_; t += TK_THREADS) tmax = max(tmax, to_key(tm_row[t * 64]));
+        } else {
+            for (int i = tid * V; i < M; i += span) {
+                unsigned key[V];
+                load_keys<T, ALIGNED>(row, keep, i, M, key);
 #pragma unroll
-            for (int j = 0; j < V; ++j) tmax = max(tmax, key[j]);
+                for (int j = 0; j < V; ++j) tmax = max(tmax, key[j]);
+            }
         }
         // ---- k-th largest thread maximum (lower bound of the k-th largest element)
         unsigned tau = 0;
@@ -124,37 +116,70 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ 
             if (c >= (unsigned)k) tau = t;
         }
         // ---- sweep 2: collect candidates >= tau
-        if (tid == 0) s_count = 0;
+        if (tid == 0) { s_count = 0; s_ntiles = 0; }
         __syncthreads();
-        for (int i0 = 0; i0 < M; i0 += span) {
-            const int i = i0 + tid * V;
-            unsigned key[V];
-            unsigned vmax = 0;
-            if (i < M) {
-                load_keys<T, ALIGNED>(row, keep, i, M, key);
-#pragma unroll
-                for (int j = 0; j < V; ++j) vmax = max(vmax, (ALIGNED || i + j < M) ? key[j] : 0u);
+        // appends this lane's hit to the candidate list (wave-aggregated LDS atomic)
+        auto push = [&](bool hit, unsigned key, int index) {
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) return;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (hit) {
+                const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < (unsigned)TK_CAP) cand[pos] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)index);
             }
-            const bool any = (i < M) && (vmax >= tau);
-            if (__ballot(any) == 0ull) continue;
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const bool hit = any && (i + j < M) && key[j] >= tau;
+        };
+        if (by_tile) {
+            // list of the blocks that can hold a candidate
+            for (int t0 = 0; t0 < T_; t0 += TK_THREADS) {
+                const int t = t0 + tid;
+                const bool hit = t < T_ && to_key(tm_row[t * 64]) >= tau;
                 const unsigned long long m = __ballot(hit);
                 if (m == 0ull) continue;
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+                if (lane == 0) base = atomicAdd(&s_ntiles, (unsigned)__popcll(m));
                 base = __shfl(base, 0, 64);
                 if (hit) {
                     const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < (unsigned)TK_CAP)
-                        cand[pos] = ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(i + j));
+                    if (pos < (unsigned)TK_TCAP) tiles[pos] = (unsigned short)t;
                 }
+            }
+            __syncthreads();
+            const unsigned nt = s_ntiles;
+            if (nt > (unsigned)TK_TCAP) {
+                exact = true;   // block-uniform
+            } else {
+                constexpr int LPT = TK_TILE / V;          // lanes per block: 16 (bf16) / 32 (f32)
+                constexpr int GPW = 64 / LPT;             // blocks per wave instruction
+                for (unsigned g0 = (unsigned)wave * GPW; g0 < nt; g0 += TK_WAVES * GPW) {
+                    const unsigned g = g0 + (unsigned)(lane / LPT);
+                    const int i = g < nt ? (int)tiles[g] * TK_TILE + (lane % LPT) * V : M;
+                    unsigned key[V];
+                    if (i < M) load_keys<T, true>(row, nullptr, i, M, key);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) push(i < M && key[j] >= tau, i < M ? key[j] : 0u, i + j);
+                }
+            }
+        } else {
+            for (int i0 = 0; i0 < M; i0 += span) {
+                const int i = i0 + tid * V;
+                unsigned key[V];
+                unsigned vmax = 0;
+                if (i < M) {
+                    load_keys<T, ALIGNED>(row, keep, i, M, key);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) vmax = max(vmax, (ALIGNED || i + j < M) ? key[j] : 0u);
+                }
+                const bool any = (i < M) && (vmax >= tau);
+                if (__ballot(any) == 0ull) continue;
+#pragma unroll
+                for (int j = 0; j < V; ++j) push(any && (i + j < M) && key[j] >= tau, any ? key[j] : 0u, i + j);
             }
         }
         __syncthreads();
         const unsigned count = s_count;
-        if (count > (unsigned)TK_CAP) {
+        if (exact || count > (unsigned)TK_CAP) {
             exact = true;   // block-uniform
         } else {
             // ---- bitonic sort, descending on (key, ~index)
@@ -296,8 +321,8 @@ __global__ __launch_bounds__(256) void groupmax_kernel(const T* __restrict__ pre
 
 }  // namespace sphip
 
-extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, int64_t N, int64_t M, int64_t k,
-                          void* vals, int64_t* idx, void* stream) {
+extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max, int64_t N,
+                          int64_t M, int64_t k, void* vals, int64_t* idx, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "topk: bad dtype %d", dtype);
     SPHIP_REQUIRE(pre && vals && idx, SPHIP_EINVAL, "topk: null pointer");
@@ -311,14 +336,14 @@ extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, 
     const bool aligned = (M % vec == 0) && (((uintptr_t)pre & 15) == 0);
     if (dtype == SPHIP_BF16) {
         if (aligned)
-            hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (int)M, (int)k, (bf16_t*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
         else
-            hipLaunchKernelGGL((topk_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (int)M, (int)k, (bf16_t*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
     } else {
         if (aligned)
-            hipLaunchKernelGGL((topk_kernel<float, true>), grid, block, 0, s, (const float*)pre, keep_mask, (int)M, (int)k, (float*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<float, true>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
         else
-            hipLaunchKernelGGL((topk_kernel<float, false>), grid, block, 0, s, (const float*)pre, keep_mask, (int)M, (int)k, (float*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<float, false>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
     }
     SPHIP_CHECK_LAUNCH("topk");
     return SPHIP_OK;

@@ -92,15 +92,21 @@ class FusedEncoder(torch.autograd.Function):
             x_low = None
             if low:
                 x_low = x2 if x2.dtype == torch.bfloat16 else ops.center_cast(x2, None, False, True)[1]
+        tile_max = None
         if low:
-            pre = ops.encoder_preacts(x_low, bf16_shadow(weight), None if bias is None else bf16_shadow(bias))
+            # the bf16 GEMM epilogue also leaves the maximum of every 128-latent block of pre;
+            # top-k then reads only the ~k blocks per row that can hold a selected latent
+            pre = ops.encoder_preacts(x_low, bf16_shadow(weight), None if bias is None else bf16_shadow(bias),
+                                      want_tile_max=(activation == "topk"))
+            if activation == "topk":
+                pre, tile_max = pre
         else:
             xf = rows if rows.dtype == torch.float32 else ops.center_cast(rows, None, True, False)[0]
             pre = ops.encoder_preacts(xf, weight.detach().contiguous(),
                                       None if bias is None else bias.detach().contiguous())
 
         if activation == "topk":
-            values, indices = ops.topk(pre, k)
+            values, indices = ops.topk(pre, k, tile_max=tile_max)
         else:
             values, indices = ops.groupmax(pre, k)
         ops.forget_segments(indices)

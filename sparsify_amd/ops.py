@@ -113,8 +113,13 @@ def cast_bf16(src: Tensor, out: Tensor | None = None) -> Tensor:
     return out
 
 
-def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True) -> Tensor:
-    """relu(x @ W.T + bias); reference: fused_encoder.py:29."""
+TOPK_TILE = 128      # SPHIP_TOPK_TILE: latents per block maximum
+
+
+def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True, want_tile_max: bool = False):
+    """relu(x @ W.T + bias); reference: fused_encoder.py:29. With want_tile_max also returns the
+    block maxima that topk() uses to skip most of each row: a (ceil(N/64), ceil(M/128), 64)
+    tensor, [n // 64, t, n % 64] = max of pre[n, 128 t : 128 (t + 1)] (rows past N undefined)."""
     _req(x, "x", ndim=2)
     _req(W, "weight", x.dtype, 2)
     if bias is not None:
@@ -124,17 +129,23 @@ def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True
     if W.shape[1] != D or (bias is not None and bias.shape[0] != M):
         raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(W.shape)}")
     pre = torch.empty(N, M, dtype=x.dtype, device=x.device)
+    tmax = torch.empty(-(-N // 64), -(-M // TOPK_TILE), 64, dtype=x.dtype, device=x.device) if want_tile_max else None
     _ev = timer.start("sphip_encoder_preacts", x)
-    check(_lib.load().sphip_encoder_preacts(x.data_ptr(), W.data_ptr(), _ptr(bias), pre.data_ptr(), _dt(x), N, D, M,
-                                           int(relu), _stream(x)), "sphip_encoder_preacts")
+    check(_lib.load().sphip_encoder_preacts(x.data_ptr(), W.data_ptr(), _ptr(bias), pre.data_ptr(), _ptr(tmax), _dt(x),
+                                           N, D, M, int(relu), _stream(x)), "sphip_encoder_preacts")
     timer.stop(_ev, x)
-    return pre
+    return (pre, tmax) if want_tile_max else pre
 
 
-def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None):
-    """torch.topk(pre, k, sorted=False) (optionally restricted to keep_mask); fused_encoder.py:33."""
+def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None, tile_max: Tensor | None = None):
+    """torch.topk(pre, k, sorted=False) (optionally restricted to keep_mask); fused_encoder.py:33.
+    tile_max: the block maxima encoder_preacts(..., want_tile_max=True) returned for this `pre`."""
     _req(pre, "pre_acts", ndim=2)
     N, M = pre.shape
+    if tile_max is not None:
+        _req(tile_max, "tile_max", pre.dtype, 3)
+        if tuple(tile_max.shape) != (-(-N // 64), -(-M // TOPK_TILE), 64):
+            raise ValueError(f"tile_max must be ({-(-N // 64)}, {-(-M // TOPK_TILE)}, 64), got {tuple(tile_max.shape)}")
     if keep_mask is not None:
         _req(keep_mask, "keep_mask", ndim=1)
         if keep_mask.dtype == torch.bool:
@@ -144,8 +155,8 @@ def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None):
     vals = torch.empty(N, k, dtype=pre.dtype, device=pre.device)
     idx = torch.empty(N, k, dtype=torch.int64, device=pre.device)
     _ev = timer.start("sphip_topk", pre)
-    check(_lib.load().sphip_topk(pre.data_ptr(), _dt(pre), _ptr(keep_mask), N, M, k, vals.data_ptr(), idx.data_ptr(),
-                                _stream(pre)), "sphip_topk")
+    check(_lib.load().sphip_topk(pre.data_ptr(), _dt(pre), _ptr(keep_mask), _ptr(tile_max), N, M, k, vals.data_ptr(),
+                                idx.data_ptr(), _stream(pre)), "sphip_topk")
     timer.stop(_ev, pre)
     return vals, idx
 

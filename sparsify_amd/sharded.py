@@ -43,12 +43,12 @@ class _ShardedEncode(torch.autograd.Function):
             rows = x2
             x_low = (x2 if x2.dtype == torch.bfloat16 else ops.center_cast(x2, None, False, True)[1]) if low else None
         if low:
-            pre = ops.encoder_preacts(x_low, bf16_shadow(weight), bf16_shadow(bias))
+            pre, tile_max = ops.encoder_preacts(x_low, bf16_shadow(weight), bf16_shadow(bias), want_tile_max=True)
         else:
             xf = rows if rows.dtype == torch.float32 else ops.center_cast(rows, None, True, False)[0]
-            pre = ops.encoder_preacts(xf, weight.detach().contiguous(), bias.detach().contiguous())
+            pre, tile_max = ops.encoder_preacts(xf, weight.detach().contiguous(), bias.detach().contiguous()), None
         kk = min(k, pre.shape[1])
-        lv, li = ops.topk(pre, kk)
+        lv, li = ops.topk(pre, kk, tile_max=tile_max)
         cand_v, cand_i = parallel.gather_topk_candidates(lv, li, lo)          # (N, W*kk)
         mv, mpos = ops.topk(cand_v.contiguous(), k)                            # merge
         gidx = cand_i.gather(1, mpos)

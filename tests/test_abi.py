@@ -33,11 +33,11 @@ def test_abi_version_and_error_reporting():
     lib = _lib.load()
     assert lib.sphip_abi_version() == _lib.ABI_VERSION
     # host-side validation happens before any launch: no GPU needed
-    st = lib.sphip_topk(None, 0, None, 1, 8, 1, None, None, None)
+    st = lib.sphip_topk(None, 0, None, None, 1, 8, 1, None, None, None)
     assert st == 1 and b"null pointer" in lib.sphip_last_error()
     st = lib.sphip_groupmax(1, 0, 4, 10, 3, 1, 1, None)
     assert st == 1 and b"not divisible" in lib.sphip_last_error()
-    st = lib.sphip_encoder_preacts(16, 16, None, 16, 1, 4, 12, 8, 1, None)
+    st = lib.sphip_encoder_preacts(16, 16, None, 16, None, 1, 4, 12, 8, 1, None)
     assert st == 2 and b"multiple of 8" in lib.sphip_last_error()
     with pytest.raises(_lib.HipLibraryError):
         _lib.check(st, "sphip_encoder_preacts")

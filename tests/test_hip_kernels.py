@@ -182,6 +182,39 @@ def test_gather_rows_weighted(device, N, k, M, D, cdtype):
     torch.testing.assert_close(got2, ref - bias, rtol=1e-5, atol=1e-5 * k**0.5)
 
 
+@pytest.mark.parametrize("N,D,M,k", [(300, 64, 1024, 32), (256, 128, 24576, 32), (64, 64, 131072, 192),
+                                      (40, 64, 1000, 17), (33, 64, 4104, 1024), (16, 64, 262144, 64)])
+@pytest.mark.parametrize("gemm", ["128", "256"])
+@pytest.mark.parametrize("relu", [True, False])
+def test_topk_with_block_maxima(device, monkeypatch, N, D, M, k, gemm, relu):
+    """Block maxima from the GEMM (epilogue of the 256 kernel / side kernel otherwise) are exact,
+    and top-k through them returns bit for bit what the full-row kernel returns -- including
+    rows of ties (relu zeros), partial last blocks and k up to the thread count."""
+    from sparsify_amd import ops
+    monkeypatch.setenv("SPHIP_GEMM", gemm)
+    torch.manual_seed(M + k)
+    x = torch.randn(N, D).bfloat16()
+    W = (torch.randn(M, D) / D**0.5).bfloat16()
+    b = (torch.randn(M) * 0.1 - (1.0 if relu else 0.0)).bfloat16()     # relu: most entries are 0 (ties)
+    pre, tmax = ops.encoder_preacts(dev(x), dev(W), dev(b), relu=relu, want_tile_max=True)
+    T = -(-M // 128)
+    padded = torch.full((N, T * 128), float("-inf"))
+    padded[:, :M] = pre.float().cpu()
+    NB = -(-N // 64)
+    got_tmax = tmax.float().cpu().permute(0, 2, 1).reshape(NB * 64, T)[:N]      # [n // 64, t, n % 64] -> [n, t]
+    assert torch.equal(got_tmax, padded.view(N, T, 128).amax(dim=2))
+    v0, i0 = ops.topk(pre, k)
+    v1, i1 = ops.topk(pre, k, tile_max=tmax)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    # fp32 rows with block maxima (side kernel)
+    pre32 = pre.float() + dev(torch.randn(N, M)) * 1e-3
+    tm32 = torch.nn.functional.pad(pre32, (0, T * 128 - M), value=float("-inf")).view(N, T, 128).amax(dim=2)
+    tm32 = torch.nn.functional.pad(tm32, (0, 0, 0, NB * 64 - N)).view(NB, 64, T).permute(0, 2, 1).contiguous()
+    v2, i2 = ops.topk(pre32, k)
+    v3, i3 = ops.topk(pre32, k, tile_max=tm32)
+    assert torch.equal(i2, i3) and torch.equal(v2, v3)
+
+
 @pytest.mark.parametrize("N,k,M,D", [(7, 13, 300, 256), (130, 192, 4096, 1024), (33, 8, 64, 4096)])
 @pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
 def test_gather_sliced_kernel_matches_full(device, monkeypatch, N, k, M, D, cdtype):
