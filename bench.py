@@ -71,6 +71,26 @@ def cpu_baseline(w: dict, tokens: int, budget_s: float = 25.0) -> dict:
                       f"the reference's (N*k,D) fp32 temporary forbids the GPU batch size on CPU"}
 
 
+def measured_traffic(kernel_prefix: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_pmc_summary.json, made by benchmarks/profile.sh: FETCH_SIZE and WRITE_SIZE in
+    runs of their own, FETCH_SIZE doubled for gfx950). Counters cannot be read inside a timed
+    run, so this is the profile's number for the same command, or None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    prof = json.load(open(files[-1]))
+    for name, d in prof.items():
+        if name.startswith(kernel_prefix) and "fetch_bytes_per_launch" in d and "write_bytes_per_launch" in d:
+            util = None
+            if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
+                # busy cycles are summed over 256 CUs x 4 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+                util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)
+            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], util
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +174,8 @@ def main():
         dec = kern["sphip_gather_rows_weighted"]
         wg = kern["sphip_segmented_weight_grad"]
         gather_bytes = N * (k * D * 4 + D * 4)                    # decode fwd per token
+        headline = args.workload.startswith("llama3-8b-layer") and N == 16384 and not args.fp32
+        traffic, mfma_util = measured_traffic("sphip::encoder_gemm256_kernel<true") if headline else (None, None)
         out = {
             "metric": "SAE train tokens/sec at d=4096, M=131072, k=192 (1-8 GPUs); MFMA util %",
             "value": N * world * args.steps / elapsed,
@@ -170,8 +192,11 @@ def main():
             "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": "signsgd",
                        "params": "fp32", "parallelism": f"dp{world}", "mean_fvu": fvu},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "encoder_gemm_kernel (sphip_encoder_preacts)", "ms": gemm["mean_ms"]},
+                         "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) from the committed "
+                                         "rocprofv3 --pmc passes of this command, profiles/r*_pmc_summary.json",
+                         "mfma_util_pct_profiled": None if mfma_util is None else 100.0 * mfma_util,
+                         "kernel": "encoder_gemm256_kernel (sphip_encoder_preacts)", "ms": gemm["mean_ms"]},
             "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in kern.items()},
             "hbm_kernels": {
                 "decode_gather_GBs": gather_bytes / (dec["total_ms"] / dec["calls"] * 1e-3) / 1e9,
