@@ -182,6 +182,25 @@ int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D
 
 /* ---------------------------------------------------------------- dead-latent bookkeeping */
 
+/* Sign exchange for data-parallel SignSGD (DDP gradient exchange, trainer.py:457-468, done as
+ * reduce-scatter of the fp32 gradients + all-gather of 1-byte signs instead of an all-reduce:
+ * SignSGD.step, sign_sgd.py:23, only needs sign(mean gradient); 5/8 of the bytes on the wire).
+ * Sign codes are int8 -1 / 0 / +1.
+ *   sphip_sign_i8:                 out = sign(g)                                (n elements)
+ *   sphip_decoder_project_sign_i8: out[j,:] = sign(G[j,:] - <G[j,:],W[j,:]> W[j,:]) for the M
+ *                                  rows given (a rank's row block of W_dec and of its reduced
+ *                                  gradient; sparse_coder.py:281-295 + sign)
+ *   sphip_apply_signs:             p -= lr * signs (optionally refreshing a bf16 shadow of p)
+ *   sphip_decoder_apply_signs:     the same per decoder row, followed by the row
+ *                                  normalisation when renorm != 0 (sparse_coder.py:273-279) */
+int sphip_sign_i8(const float* g, int64_t n, int8_t* out, void* stream);
+int sphip_decoder_project_sign_i8(const float* W, const float* G, int64_t M, int64_t D,
+                                  int8_t* out, void* stream);
+int sphip_apply_signs(float* p, const int8_t* signs, int64_t n, float lr, void* bf16_shadow,
+                      void* stream);
+int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr,
+                              int renorm, void* stream);
+
 /* trainer.py:422: did_fire[idx.flatten()] = True.  did_fire (M) uint8. */
 int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire,
                      void* stream);

@@ -67,6 +67,9 @@ class TrainConfig(_Serializable):
     layers: list[int] = field(default_factory=list)
     layer_stride: int = 1
     distribute_modules: bool = False
+    exchange_signs: bool = True
+    """(not in the reference) "signsgd" optimizer under DDP: exchange the large gradients as
+    reduce-scatter + all-gather of 1-byte signs instead of an fp32 all-reduce (same update)."""
     save_every: int = 1000
     save_best: bool = False
     finetune: str | None = None

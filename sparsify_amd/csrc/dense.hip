@@ -212,6 +212,125 @@ __global__ __launch_bounds__(256) void signsgd_kernel(float* __restrict__ p, con
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sign exchange for data-parallel SignSGD (parallel.py: reduce-scatter of the gradients, each
+// rank takes the sign of its row block, all-gather of 1-byte signs, every rank applies them).
+// sign codes: -1, 0, +1 as int8.
+__device__ __forceinline__ int sgn(float v) { return (v > 0.f) - (v < 0.f); }
+__device__ __forceinline__ unsigned pack_signs(float4 v) {
+    return (unsigned)(sgn(v.x) & 0xff) | ((unsigned)(sgn(v.y) & 0xff) << 8) | ((unsigned)(sgn(v.z) & 0xff) << 16) |
+           ((unsigned)(sgn(v.w) & 0xff) << 24);
+}
+__device__ __forceinline__ float4 unpack_signs(unsigned u) {
+    return make_float4((float)(signed char)(u & 0xff), (float)(signed char)((u >> 8) & 0xff),
+                       (float)(signed char)((u >> 16) & 0xff), (float)(signed char)(u >> 24));
+}
+
+__global__ __launch_bounds__(256) void sign_i8_kernel(const float* __restrict__ g, int64_t n, signed char* __restrict__ out) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<unsigned*>(out)[i] = pack_signs(*reinterpret_cast<const float4*>(g + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        out[i] = (signed char)sgn(g[i]);
+    }
+}
+
+// out[j,:] = sign(G[j,:] - <G[j,:],W[j,:]> W[j,:]); row-resident (D <= 1024 R) or two sweeps (R = 0)
+template <int R>
+__global__ __launch_bounds__(256) void project_sign_i8_kernel(const float* __restrict__ W, const float* __restrict__ G,
+                                                              int D, signed char* __restrict__ out) {
+    __shared__ float red[16];
+    const float* w = W + (int64_t)blockIdx.x * D;
+    const float* g = G + (int64_t)blockIdx.x * D;
+    signed char* o = out + (int64_t)blockIdx.x * D;
+    if (R > 0) {
+        float4 b[R > 0 ? R : 1], a[R > 0 ? R : 1];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int c = (threadIdx.x + 256 * i) * 4;
+            b[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[i] = c < D ? *reinterpret_cast<const float4*>(g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            acc = fmaf(a[i].x, b[i].x, acc); acc = fmaf(a[i].y, b[i].y, acc);
+            acc = fmaf(a[i].z, b[i].z, acc); acc = fmaf(a[i].w, b[i].w, acc);
+        }
+        const float par = block_sum(acc, red);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int c = (threadIdx.x + 256 * i) * 4;
+            if (c < D)
+                *reinterpret_cast<unsigned*>(o + c) = pack_signs(make_float4(
+                    a[i].x - par * b[i].x, a[i].y - par * b[i].y, a[i].z - par * b[i].z, a[i].w - par * b[i].w));
+        }
+    } else {
+        float acc = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) acc = fmaf(g[c], w[c], acc);
+        const float par = block_sum(acc, red);
+        for (int c = threadIdx.x; c < D; c += 256) o[c] = (signed char)sgn(g[c] - par * w[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_signs_kernel(float* __restrict__ p, const signed char* __restrict__ sg,
+                                                          int64_t n, float lr, bf16_t* __restrict__ shadow) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = *reinterpret_cast<const float4*>(p + i * 4);
+        const float4 t = unpack_signs(reinterpret_cast<const unsigned*>(sg)[i]);
+        v.x -= lr * t.x; v.y -= lr * t.y; v.z -= lr * t.z; v.w -= lr * t.w;
+        *reinterpret_cast<float4*>(p + i * 4) = v;
+        if (shadow != nullptr) {
+            const unsigned lo = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+            const unsigned hi = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>(shadow + i * 4) = make_uint2(lo, hi);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float v = p[i] - lr * (float)sg[i];
+        p[i] = v;
+        if (shadow != nullptr) shadow[i] = f32_to_bf16(v);
+    }
+}
+
+// W[j,:] -= lr * signs[j,:], then W[j,:] /= ||W[j,:]|| + eps (same arithmetic order as
+// decoder_row_resident_kernel<R, 2>, so the data-parallel step equals the single-GPU one)
+template <int R>
+__global__ __launch_bounds__(256) void apply_signs_norm_kernel(float* __restrict__ W, const signed char* __restrict__ sg,
+                                                               int D, float lr, float eps) {
+    __shared__ float red[16];
+    float* w = W + (int64_t)blockIdx.x * D;
+    const signed char* t = sg + (int64_t)blockIdx.x * D;
+    float4 b[R];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 4;
+        b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < D) {
+            b[i] = *reinterpret_cast<const float4*>(w + c);
+            const float4 u = unpack_signs(*reinterpret_cast<const unsigned*>(t + c));
+            b[i].x -= lr * u.x; b[i].y -= lr * u.y; b[i].z -= lr * u.z; b[i].w -= lr * u.w;
+            acc = fmaf(b[i].x, b[i].x, acc); acc = fmaf(b[i].y, b[i].y, acc);
+            acc = fmaf(b[i].z, b[i].z, acc); acc = fmaf(b[i].w, b[i].w, acc);
+        }
+    }
+    const float denom = sqrtf(block_sum(acc, red)) + eps;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = (threadIdx.x + 256 * i) * 4;
+        if (c < D) {
+            b[i].x /= denom; b[i].y /= denom; b[i].z /= denom; b[i].w /= denom;
+            *reinterpret_cast<float4*>(w + c) = b[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mark_fired_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t M,
                                                          uint8_t* __restrict__ fired) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -348,6 +467,65 @@ extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr,
     hipLaunchKernelGGL(signsgd_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, n, lr, (bf16_t*)bf16_shadow);
     SPHIP_CHECK_LAUNCH("signsgd_step");
     return SPHIP_OK;
+}
+
+extern "C" int sphip_sign_i8(const float* g, int64_t n, int8_t* out, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(g && out, SPHIP_EINVAL, "sign_i8: null pointer");
+    SPHIP_REQUIRE(n > 0, SPHIP_EINVAL, "sign_i8: empty");
+    SPHIP_REQUIRE(((uintptr_t)g & 15) == 0 && ((uintptr_t)out & 3) == 0, SPHIP_EINVAL, "sign_i8: operands must be aligned (16 B / 4 B)");
+    hipLaunchKernelGGL(sign_i8_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, g, n, (signed char*)out);
+    SPHIP_CHECK_LAUNCH("sign_i8");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_decoder_project_sign_i8(const float* W, const float* G, int64_t M, int64_t D, int8_t* out, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && G && out, SPHIP_EINVAL, "decoder_project_sign_i8: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "decoder_project_sign_i8: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)M), block(256);
+    signed char* o = (signed char*)out;
+    const bool vec = D % 4 == 0 && D <= 8192 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)out & 3) == 0;
+    if (!vec) hipLaunchKernelGGL((project_sign_i8_kernel<0>), grid, block, 0, s, W, G, (int)D, o);
+    else if (D <= 1024) hipLaunchKernelGGL((project_sign_i8_kernel<1>), grid, block, 0, s, W, G, (int)D, o);
+    else if (D <= 2048) hipLaunchKernelGGL((project_sign_i8_kernel<2>), grid, block, 0, s, W, G, (int)D, o);
+    else if (D <= 4096) hipLaunchKernelGGL((project_sign_i8_kernel<4>), grid, block, 0, s, W, G, (int)D, o);
+    else hipLaunchKernelGGL((project_sign_i8_kernel<8>), grid, block, 0, s, W, G, (int)D, o);
+    SPHIP_CHECK_LAUNCH("decoder_project_sign_i8");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_apply_signs(float* p, const int8_t* signs, int64_t n, float lr, void* bf16_shadow, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(p && signs, SPHIP_EINVAL, "apply_signs: null pointer");
+    SPHIP_REQUIRE(n > 0, SPHIP_EINVAL, "apply_signs: empty");
+    SPHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)signs & 3) == 0 && ((uintptr_t)bf16_shadow & 7) == 0, SPHIP_EINVAL,
+                  "apply_signs: operands must be aligned (16 B / 4 B / 8 B)");
+    hipLaunchKernelGGL(apply_signs_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, (const signed char*)signs, n, lr, (bf16_t*)bf16_shadow);
+    SPHIP_CHECK_LAUNCH("apply_signs");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr, int renorm, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && signs, SPHIP_EINVAL, "decoder_apply_signs: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "decoder_apply_signs: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const signed char* t = (const signed char*)signs;
+    const bool vec = D % 4 == 0 && D <= 8192 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)signs & 3) == 0;
+    if (renorm && vec) {
+        dim3 grid((unsigned)M), block(256);
+        if (D <= 1024) hipLaunchKernelGGL((apply_signs_norm_kernel<1>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
+        else if (D <= 2048) hipLaunchKernelGGL((apply_signs_norm_kernel<2>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
+        else if (D <= 4096) hipLaunchKernelGGL((apply_signs_norm_kernel<4>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
+        else hipLaunchKernelGGL((apply_signs_norm_kernel<8>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
+        SPHIP_CHECK_LAUNCH("decoder_apply_signs");
+        return SPHIP_OK;
+    }
+    const int st = sphip_apply_signs(W, signs, M * D, lr, nullptr, stream);
+    if (st != SPHIP_OK || !renorm) return st;
+    return sphip_unit_norm_rows(W, M, D, stream);
 }
 
 extern "C" int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire, void* stream) {

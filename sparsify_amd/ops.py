@@ -363,6 +363,55 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
     return p
 
 
+# ---- sign exchange (data-parallel SignSGD, parallel.SignExchange)
+def sign_i8(g: Tensor, out: Tensor | None = None) -> Tensor:
+    """int8 sign(g) (-1 / 0 / +1)."""
+    _req(g, "grad", torch.float32)
+    if out is None:
+        out = torch.empty(g.shape, dtype=torch.int8, device=g.device)
+    _req(out, "signs", torch.int8)
+    check(_lib.load().sphip_sign_i8(g.data_ptr(), g.numel(), out.data_ptr(), _stream(g)), "sphip_sign_i8")
+    return out
+
+
+def decoder_project_sign_i8(W_rows: Tensor, G_rows: Tensor, out: Tensor | None = None) -> Tensor:
+    """int8 sign(G - <G,W> W) per row, for a block of decoder rows and its gradient."""
+    _req(W_rows, "W_dec rows", torch.float32, 2)
+    _req(G_rows, "W_dec.grad rows", torch.float32, 2)
+    if W_rows.shape != G_rows.shape:
+        raise ValueError("decoder_project_sign_i8: shape mismatch")
+    if out is None:
+        out = torch.empty(G_rows.shape, dtype=torch.int8, device=G_rows.device)
+    _req(out, "signs", torch.int8)
+    check(_lib.load().sphip_decoder_project_sign_i8(W_rows.data_ptr(), G_rows.data_ptr(), W_rows.shape[0], W_rows.shape[1],
+                                                   out.data_ptr(), _stream(W_rows)), "sphip_decoder_project_sign_i8")
+    return out
+
+
+def apply_signs_(p: Tensor, signs: Tensor, lr: float, bf16_shadow: Tensor | None = None) -> Tensor:
+    """p -= lr * signs (int8), optionally refreshing the bf16 shadow of p."""
+    _req(p, "param", torch.float32)
+    _req(signs, "signs", torch.int8)
+    if signs.numel() != p.numel():
+        raise ValueError("apply_signs: size mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    check(_lib.load().sphip_apply_signs(p.data_ptr(), signs.data_ptr(), p.numel(), float(lr), _ptr(bf16_shadow),
+                                       _stream(p)), "sphip_apply_signs")
+    return p
+
+
+def decoder_apply_signs_(W: Tensor, signs: Tensor, lr: float, renorm: bool = False) -> Tensor:
+    """W -= lr * signs per decoder row; renorm=True also re-normalises the updated rows."""
+    _req(W, "W_dec", torch.float32, 2)
+    _req(signs, "signs", torch.int8)
+    if signs.numel() != W.numel():
+        raise ValueError("decoder_apply_signs: size mismatch")
+    check(_lib.load().sphip_decoder_apply_signs(W.data_ptr(), signs.data_ptr(), W.shape[0], W.shape[1], float(lr),
+                                               int(renorm), _stream(W)), "sphip_decoder_apply_signs")
+    return W
+
+
 def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = False) -> Tensor:
     """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows."""
     _req(W, "W_dec", torch.float32, 2)

@@ -110,6 +110,47 @@ class GradReducer:
                 p.grad /= w
 
 
+class SignExchange:
+    """Gradient exchange of data-parallel SignSGD for the large matrices: the update only needs
+    sign(mean gradient), so instead of all-reducing 4 B per element both ways
+    (reduce-scatter + all-gather inside the all-reduce), the fp32 gradients are
+    reduce-scattered by row blocks, each rank takes the sign of its block (for the decoder:
+    of the projected gradient, a row-local operation), and 1-byte signs are all-gathered:
+    (4 + 1) / (4 + 4) of the bytes over xGMI, and the result is exactly the update of the
+    averaged gradient (trainer.py:457-468 + sign_sgd.py:23).
+
+    `sign_fn(grad_rows, row_lo, row_hi) -> int8 signs` and `apply_fn(signs_full)` are the
+    per-parameter kernels (sign_sgd.SignSGD passes the HIP ones)."""
+
+    MIN_NUMEL = 1 << 20
+
+    @staticmethod
+    def eligible(p: Tensor) -> bool:
+        w = world_size()
+        return w > 1 and p.ndim == 2 and p.shape[0] % w == 0 and p.numel() >= SignExchange.MIN_NUMEL
+
+    @staticmethod
+    def step(grad: Tensor, sign_fn, apply_fn) -> None:
+        w, r = world_size(), rank()
+        rows = grad.shape[0] // w
+        grad = grad.contiguous()
+        shard = torch.empty(rows, *grad.shape[1:], dtype=grad.dtype, device=grad.device)
+        if dist.get_backend() == "nccl":
+            dist.reduce_scatter_tensor(shard, grad, op=dist.ReduceOp.AVG)
+        elif _host_staged(grad):
+            h = torch.empty(shard.shape, dtype=shard.dtype)
+            dist.reduce_scatter_tensor(h, grad.cpu(), op=dist.ReduceOp.SUM)
+            shard.copy_(h)
+            shard /= w
+        else:
+            dist.reduce_scatter_tensor(shard, grad, op=dist.ReduceOp.SUM)
+            shard /= w
+        signs = sign_fn(shard, r * rows, (r + 1) * rows)
+        full = torch.empty(grad.shape, dtype=torch.int8, device=grad.device)
+        _all_gather_raw(full, signs.contiguous())
+        apply_fn(full)
+
+
 def broadcast_parameters(params, src: int = 0):
     """What DDP does at wrap time (trainer.py:463): make replicas identical."""
     if world_size() > 1:

@@ -165,7 +165,7 @@ class Trainer:
                     if dec:
                         pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
-                self.optimizers = [SignSGD(pgs)]
+                self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs)]
                 self._fused_projection = project
             case other:
                 raise ValueError(f"Unknown optimizer '{other}'")
@@ -207,7 +207,9 @@ class Trainer:
             return
         params = [p for sae in self.saes.values() for p in sae.parameters()]
         parallel.broadcast_parameters(params)
-        self._reducer = parallel.GradReducer(params)
+        # parameters whose gradients the optimizer exchanges itself (SignSGD sign exchange)
+        own = [opt.reduces for opt in self.optimizers if hasattr(opt, "reduces")]
+        self._reducer = parallel.GradReducer([p for p in params if not any(f(p) for f in own)])
         self._hooks_installed = True
 
     def _finish_grad_reduce(self):

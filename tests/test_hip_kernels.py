@@ -384,6 +384,35 @@ def test_decoder_row_kernels_fused_vs_separate(device, M, D):
     torch.testing.assert_close(Wb.cpu().norm(dim=1), torch.ones(M), rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("M,D", [(64, 48), (100, 1024), (37, 1028), (50, 4096), (5, 8196), (3, 50)])
+def test_sign_exchange_kernels(device, M, D):
+    """sign -> int8 -> apply is bit for bit the fused SignSGD / decoder step (the data-parallel
+    sign exchange must produce the single-GPU update)."""
+    from sparsify_amd import ops
+    torch.manual_seed(M * D)
+    W0 = O.unit_norm_rows(torch.randn(M, D))
+    G = torch.randn(M, D)
+    G[0, : D // 2] = 0.0                                        # exact zeros keep sign 0
+    sg = ops.sign_i8(dev(G))
+    assert torch.equal(sg.cpu(), torch.sign(G).to(torch.int8))
+    # plain parameter (+ bf16 shadow)
+    pa, pb = dev(W0.clone()), dev(W0.clone())
+    sha, shb = torch.empty_like(pa, dtype=torch.bfloat16), torch.empty_like(pb, dtype=torch.bfloat16)
+    ops.signsgd_step_(pa, dev(G), 3e-3, sha)
+    ops.apply_signs_(pb, sg, 3e-3, shb)
+    assert torch.equal(pa, pb) and torch.equal(sha, shb)
+    # decoder rows: projected sign by row blocks, then apply (+ renorm)
+    half = M // 2
+    Wd = dev(W0)
+    ps = torch.cat([ops.decoder_project_sign_i8(Wd[:half].contiguous(), dev(G[:half].contiguous())),
+                    ops.decoder_project_sign_i8(Wd[half:].contiguous(), dev(G[half:].contiguous()))])
+    for renorm in (False, True):
+        wa, wb = dev(W0.clone()), dev(W0.clone())
+        ops.decoder_project_signsgd_(wa, dev(G), 3e-3, renorm)
+        ops.decoder_apply_signs_(wb, ps, 3e-3, renorm)
+        assert torch.equal(wa, wb)
+
+
 def test_dead_latent_bookkeeping(device):
     from sparsify_amd import ops
     M = 1000

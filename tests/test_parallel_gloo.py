@@ -115,3 +115,41 @@ def _sharded_topk(rank, world):
 
 def test_latent_sharded_topk_merge_equals_global_topk():
     assert all(launch(_sharded_topk))
+
+
+def _sign_exchange(rank, world):
+    """parallel.SignExchange with torch stand-ins for the two HIP kernels: the update must be
+    the SignSGD step on the rank-averaged gradient (plain and decoder-projected)."""
+    from sparsify_amd import parallel as P
+    torch.manual_seed(0)
+    M, D, lr = 8, 131072, 1e-2                      # >= MIN_NUMEL, M divisible by the world size
+    W = torch.randn(M, D)
+    W /= W.norm(dim=1, keepdim=True)
+    grads = [torch.randn(M, D, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    mean = sum(grads) / world
+    assert P.SignExchange.eligible(W) and not P.SignExchange.eligible(torch.zeros(7, D)) \
+        and not P.SignExchange.eligible(torch.zeros(D))
+    # plain
+    p = W.clone()
+    P.SignExchange.step(grads[rank], lambda s, lo, hi: torch.sign(s).to(torch.int8),
+                        lambda signs: p.sub_(lr * signs.float()))
+    ok_plain = torch.equal(p, W - lr * torch.sign(mean))
+    # decoder: sign of the projected gradient, taken on this rank's row block only
+    q = W.clone()
+    seen = []
+
+    def proj_sign(shard, lo, hi):
+        seen.append((lo, hi))
+        w = W[lo:hi]
+        return torch.sign(shard - (shard * w).sum(1, keepdim=True) * w).to(torch.int8)
+
+    P.SignExchange.step(grads[rank], proj_sign, lambda signs: q.sub_(lr * signs.float()))
+    ref = W - lr * torch.sign(mean - (mean * W).sum(1, keepdim=True) * W)
+    frac_bad = float((q != ref).float().mean())      # summation order of the reduce may flip a ~0 sign
+    return ok_plain, frac_bad, seen[0] == (rank * M // world, (rank + 1) * M // world)
+
+
+def test_sign_exchange_equals_step_on_mean_gradient():
+    for ok_plain, frac_bad, block_ok in launch(_sign_exchange):
+        assert ok_plain and block_ok
+        assert frac_bad < 1e-5
