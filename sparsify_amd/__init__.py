@@ -8,8 +8,10 @@ from .fused_encoder import EncoderOutput, FusedEncoder, fused_encoder
 from .sign_sgd import SignSGD
 from .sparse_coder import ForwardOutput, Sae, SparseCoder
 from .utils import decoder_impl, hip_decode
+from .trainer import Trainer
+from .driver import ModelTrainer
 
 __all__ = [
-    "EncoderOutput", "ForwardOutput", "FusedEncoder", "Sae", "SaeConfig", "SignSGD", "SparseCoder",
-    "SparseCoderConfig", "TrainConfig", "TranscoderConfig", "decoder_impl", "fused_encoder", "hip_decode",
+    "EncoderOutput", "ForwardOutput", "FusedEncoder", "ModelTrainer", "Sae", "SaeConfig", "SignSGD", "SparseCoder",
+    "SparseCoderConfig", "TrainConfig", "Trainer", "TranscoderConfig", "decoder_impl", "fused_encoder", "hip_decode",
 ]

@@ -1,0 +1,104 @@
+"""On-the-fly activation driver (sparsify_amd/driver.py; reference trainer.py:38-90, :333-508,
+utils.py:20-61). Hookpoint / width resolution runs on CPU; the train loop needs the GPU."""
+import pytest
+import torch
+
+
+def tiny_lm(layers=3, hidden=64, vocab=128):
+    from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    torch.manual_seed(0)
+    cfg = GPTNeoXConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=4,
+                        intermediate_size=2 * hidden, max_position_embeddings=64)
+    return GPTNeoXForCausalLM(cfg).eval()
+
+
+def test_hookpoint_and_width_resolution():
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.driver import get_layer_list, resolve_hookpoints, resolve_widths
+    m = tiny_lm(layers=12)
+    name, mods = get_layer_list(m)
+    assert name == "layers" and len(mods) == 12
+    # wildcards, natural order (layers.2 before layers.10), trainer.py:41-48
+    pts = resolve_hookpoints(m, TrainConfig(sae=SparseCoderConfig(), hookpoints=["layers.*.mlp"]))
+    assert pts == [f"layers.{i}.mlp" for i in range(12)]
+    # layers -> hookpoints, all layers by default, stride (trainer.py:50-59)
+    assert resolve_hookpoints(m, TrainConfig(sae=SparseCoderConfig(), layers=[1, 5])) == ["layers.1", "layers.5"]
+    assert resolve_hookpoints(m, TrainConfig(sae=SparseCoderConfig(), layer_stride=4)) == ["layers.0", "layers.4", "layers.8"]
+    with pytest.raises(AssertionError):
+        resolve_hookpoints(m, TrainConfig(sae=SparseCoderConfig(), hookpoints=["layers.0"], layers=[0]))
+    widths = resolve_widths(m, ["layers.3", "layers.3.mlp.dense_h_to_4h", "embed_in"])
+    assert widths == {"layers.3": 64, "layers.3.mlp.dense_h_to_4h": 128, "embed_in": 64}
+
+
+class _Capture:
+    """The same activations the driver sees, captured with plain hooks (for the base Trainer)."""
+
+    def __init__(self, model, points, transcode):
+        self.model, self.points, self.transcode = model, points, transcode
+
+    @torch.no_grad()
+    def __call__(self, x):
+        got = {}
+
+        def mk(name):
+            def hook(mod, inputs, outputs):
+                i = inputs[0] if isinstance(inputs, tuple) else inputs
+                o = outputs[0] if isinstance(outputs, tuple) else outputs
+                got[name] = (i.detach().clone(), o.detach().clone()) if self.transcode else o.detach().clone()
+            return hook
+
+        hs = [self.model.base_model.get_submodule(p).register_forward_hook(mk(p)) for p in self.points]
+        try:
+            self.model(x)
+        finally:
+            for h in hs:
+                h.remove()
+        return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transcode", [False, True])
+def test_model_trainer_equals_trainer_on_captured_activations(device, transcode):
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.driver import ModelTrainer
+    from sparsify_amd.trainer import Trainer
+    model = tiny_lm().cuda()
+    S, B, steps, vocab = 32, 8, 6, 128
+    g = torch.Generator().manual_seed(1)
+    data = torch.randint(0, vocab, (B * steps + 3, S), generator=g)         # 3 leftover sequences are dropped
+    pats = ["layers.*.mlp"] if transcode else ["layers.[02]"]
+
+    def cfg():
+        return TrainConfig(sae=SparseCoderConfig(num_latents=512, k=8, transcode=transcode), optimizer="signsgd", lr=1e-3,
+                           hookpoints=list(pats), batch_size=B, exclude_tokens=[0, 5], init_seeds=[0, 7],
+                           save_dir="", save_every=10**9, wandb_log_frequency=1)
+
+    mt = ModelTrainer(cfg(), data, model)
+    points = mt.cfg.hookpoints
+    assert points == (["layers.0.mlp", "layers.1.mlp", "layers.2.mlp"] if transcode else ["layers.0", "layers.2"])
+    assert set(mt.saes) == {f"{p}/seed{s}" for p in points for s in (0, 7)}          # trainer.py:83-87
+    mt.fit()
+    assert mt.global_step == steps
+
+    class Src:
+        widths = {p: 64 for p in points}
+
+        def __len__(self):
+            return steps
+
+    c2 = cfg()
+    c2.hookpoints = list(points)
+    base = Trainer(c2, Src(), device="cuda")
+    cap = _Capture(model, points, transcode)
+    fvus = []
+    for s in range(steps):
+        x = data[s * B: (s + 1) * B].cuda()
+        mask = torch.isin(x, torch.tensor([0, 5], device="cuda"), invert=True)
+        base.train_micro_batch(cap(x), mask)
+        fvus.append(base.last_logged[f"fvu/{points[0]}/seed0"])
+    for name, sae in mt.saes.items():
+        for (n1, p1), (n2, p2) in zip(sae.named_parameters(), base.saes[name].named_parameters()):
+            assert torch.equal(p1, p2), f"{name}.{n1}"
+    assert torch.equal(mt.num_tokens_since_fired[f"{points[0]}/seed0"], base.num_tokens_since_fired[f"{points[0]}/seed0"])
+    assert fvus[-1] < fvus[0]
+    assert mt.last_logged[f"fvu/{points[0]}/seed0"] == fvus[-1]
