@@ -5,8 +5,9 @@
 //
 // gfx950 design: one 1024-thread workgroup (16 waves) per token row; keys are the
 // order-preserving unsigned image of the value bits (16 bit for bf16, 32 bit for f32).
-//   fast path  (k <= 1024): sweep 1 takes each thread's maximum key; the k-th largest of
-//              the 1024 thread maxima (bisection on the key bits, one barrier per bit) is a
+//   fast path  (k <= 3072): sweep 1 takes each thread's maximum key (for k > 1024: the maxima
+//              of up to 4 interleaved groups of its chunks); the k-th largest of
+//              these maxima (bisection on the key bits, one barrier per bit) is a
 //              proven lower bound tau of the k-th largest element. Sweep 2 (row now in
 //              L2 / Infinity Cache) appends every element >= tau to an LDS candidate list
 //              (wave-aggregated LDS atomic), typically ~1.1 k entries. A bitonic sort of the
@@ -26,7 +27,8 @@ namespace sphip {
 
 constexpr int TK_THREADS = 1024;
 constexpr int TK_WAVES = TK_THREADS / 64;
-constexpr int TK_CAP = 4096;   // candidate capacity (8 B each -> 32 KB LDS)
+constexpr int TK_CAP = 8192;   // candidate capacity (8 B each -> 64 KB LDS)
+constexpr int TK_GROUPS = 4;   // maxima kept per thread: the fast path covers k <= 4 * 1024
 constexpr int TK_TILE = SPHIP_TOPK_TILE;   // latents per block maximum (sphip_encoder_preacts)
 constexpr int TK_TCAP = 2048;  // selected-block list capacity
 
@@ -41,9 +43,13 @@ __device__ __forceinline__ void load_keys(const T* row, const uint8_t* keep, int
 #pragma unroll
         for (int j = 0; j < V; ++j) key[j] = to_key(e[j]);
         if (keep != nullptr) {
+            // V mask bytes in one load (the launcher checks the mask's alignment for ALIGNED)
+            unsigned long long kb;
+            if (V == 8) kb = *reinterpret_cast<const unsigned long long*>(keep + i);
+            else kb = *reinterpret_cast<const unsigned*>(keep + i);
 #pragma unroll
             for (int j = 0; j < V; ++j)
-                if (!keep[i + j]) key[j] = 0;
+                if (((kb >> (8 * j)) & 0xffull) == 0ull) key[j] = 0;
         }
     } else {
 #pragma unroll
@@ -88,30 +94,43 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ 
     const int span = TK_THREADS * V;
     int slot = 0;
 
-    bool exact = k > TK_THREADS;
+    // group maxima per thread in use: about twice as many maxima as k, so that tau (the k-th
+    // largest of them) sits near their median and not at their minimum
+    bool exact = k > 3 * TK_THREADS;
+    const int R = k <= TK_THREADS / 2 ? 1 : (k <= TK_THREADS ? 2 : TK_GROUPS);
     if (!exact) {
         const int T_ = (M + TK_TILE - 1) / TK_TILE;
         // (fewer blocks than k: their maxima bound nothing, take the plain sweep)
-        const bool by_tile = ALIGNED && tile_max != nullptr && keep == nullptr && T_ <= 65536 && T_ >= k;
+        const bool by_tile = ALIGNED && tile_max != nullptr && keep == nullptr && T_ <= 65536 && T_ >= k && k <= TK_THREADS;
         // block maxima of this token: element t at tm_row[t * 64] (layout: sparsify_hip.h)
         const T* tm_row = tile_max + (int64_t)(blockIdx.x >> 6) * T_ * 64 + (blockIdx.x & 63);
         // ---- sweep 1: thread maxima (over the block maxima when they are given)
-        unsigned tmax = 0;
+        // every maximum is a distinct element of the row, so the k-th largest of them bounds
+        // the k-th largest element from below
+        unsigned tmax[TK_GROUPS] = {0u, 0u, 0u, 0u};
         if (by_tile) {
-            for (int t = tid; t < T_; t += TK_THREADS) tmax = max(tmax, to_key(tm_row[t * 64]));
+            for (int t = tid; t < T_; t += TK_THREADS) tmax[0] = max(tmax[0], to_key(tm_row[t * 64]));
         } else {
-            for (int i = tid * V; i < M; i += span) {
+            int c = 0;
+            for (int i = tid * V; i < M; i += span, ++c) {
                 unsigned key[V];
                 load_keys<T, ALIGNED>(row, keep, i, M, key);
+                unsigned m = 0;
 #pragma unroll
-                for (int j = 0; j < V; ++j) tmax = max(tmax, key[j]);
+                for (int j = 0; j < V; ++j) m = max(m, key[j]);
+                const int grp = R == 1 ? 0 : c % R;
+#pragma unroll
+                for (int r = 0; r < TK_GROUPS; ++r) tmax[r] = (r == grp) ? max(tmax[r], m) : tmax[r];
             }
         }
         // ---- k-th largest thread maximum (lower bound of the k-th largest element)
         unsigned tau = 0;
         for (int bit = BITS - 1; bit >= 0; --bit) {
             const unsigned t = tau | (1u << bit);
-            const unsigned c = block_count(tmax >= t ? 1u : 0u, part, slot);
+            unsigned mine = 0;
+#pragma unroll
+            for (int r = 0; r < TK_GROUPS; ++r) mine += (tmax[r] >= t) ? 1u : 0u;
+            const unsigned c = block_count(mine, part, slot);
             slot ^= 1;
             if (c >= (unsigned)k) tau = t;
         }
@@ -333,7 +352,7 @@ extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)N), block(TK_THREADS);
     const int vec = dtype == SPHIP_BF16 ? 8 : 4;
-    const bool aligned = (M % vec == 0) && (((uintptr_t)pre & 15) == 0);
+    const bool aligned = (M % vec == 0) && (((uintptr_t)pre & 15) == 0) && (((uintptr_t)keep_mask & 7) == 0);
     if (dtype == SPHIP_BF16) {
         if (aligned)
             hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);

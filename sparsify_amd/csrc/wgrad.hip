@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 // and lanes 0, 8, .., 56 store 8 consecutive floats of the slab[slice][position] array;
 // seg_dcoeff_kernel then sums the slices in a fixed order. Entry metadata is wave-uniform
 // (scalar loads). gW is summed in segment order: bitwise the same as the full-row kernel.
-template <typename RT>
+template <typename RT, bool DOT>
 __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __restrict__ packed,
                                                              const int* __restrict__ seg_begin,
                                                              const RT* __restrict__ rows,
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
     const int slice = blockIdx.y;
     const int col = slice * 256 + lane * 4;
     const int beg = seg_begin[j], end = seg_begin[j + 1];
-    const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)j * D + col);
+    const float4 w = DOT ? *reinterpret_cast<const float4*>(W + (int64_t)j * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float bsum = 0.f;
     const RT* rcol = rows + col;
@@ -292,8 +292,9 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
                 acc.w = fmaf(c[u], r[u].w, acc.w);
                 bsum += c[u];
             }
-            d[u] = fmaf(r[u].w, w.w, fmaf(r[u].z, w.z, fmaf(r[u].y, w.y, r[u].x * w.x)));
+            if (DOT) d[u] = fmaf(r[u].w, w.w, fmaf(r[u].z, w.z, fmaf(r[u].y, w.y, r[u].x * w.x)));
         }
+        if (!DOT) continue;
         // transposing butterfly: 8 values x 64 lanes -> lane l holds the wave sum of d[l >> 3]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -423,8 +424,33 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, dcoeff);
     else
         hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, dcoeff);
-    const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" (tests)
-    if (!dot && !(force && force[0] == 'f')) {
+    const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" | "wide" (tests)
+    // wide-sliced kernel: always for dcoeff at training sizes; without dcoeff only for long
+    // segments (AuxK: N*k_aux entries over the few dead latents), where the 8-latents-per-wave
+    // L2-sliced kernel would run one 8-lane group per wave
+    const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
+    const bool want_wide = dot ? ((force && force[0] == 's') || (big && N * k >= 4 * M))
+                               : ((force && force[0] == 'w') || (big && N * k >= 64 * M));
+    if (wide_eligible(D) && !(force && force[0] == 'f') && want_wide) {
+        float* slab = (float*)rows_sm;
+        const FastDiv kd = make_fastdiv((unsigned)k);
+        dim3 grid((unsigned)cdiv(M, 4), (unsigned)(D / 256)), block(256);
+        if (rows_dtype == SPHIP_F32) {
+            if (dot) hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+            else hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+        } else {
+            if (dot) hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+            else hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
+        }
+        SPHIP_CHECK_LAUNCH("segmented_weight_grad(wide)");
+        if (!dot) return SPHIP_OK;
+        // positions >= seg_begin[M] belong to inactive slots (zeroed by seg_pack_kernel); the
+        // device-side bound is read by the kernel, the grid covers all E positions
+        hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 256), dcoeff);
+        SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
+        return SPHIP_OK;
+    }
+    if (!dot && !(force && (force[0] == 'f' || force[0] == 'w'))) {
         const bool done = rows_dtype == SPHIP_F32
                               ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s)
                               : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s);
@@ -432,22 +458,6 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
         }
-    }
-    if (dot && wide_eligible(D) && !(force && force[0] == 'f') &&
-        ((force && force[0] == 's') || (N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20) && N * k >= 4 * M))) {
-        float* slab = (float*)rows_sm;
-        const FastDiv kd = make_fastdiv((unsigned)k);
-        dim3 grid((unsigned)cdiv(M, 4), (unsigned)(D / 256)), block(256);
-        if (rows_dtype == SPHIP_F32)
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
-        else
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, slab, row_shift, kd, E, (int)M, (int)D);
-        SPHIP_CHECK_LAUNCH("segmented_weight_grad(wide)");
-        // positions >= seg_begin[M] belong to inactive slots (zeroed by seg_pack_kernel); the
-        // device-side bound is read by the kernel, the grid covers all E positions
-        hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 256), dcoeff);
-        SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
-        return SPHIP_OK;
     }
     if (rows_dtype == SPHIP_F32) {
         if (dot) launch_nv<float, true>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);

@@ -99,7 +99,8 @@ def check_topk(pre_cpu, k, vals, idx, keep=None):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,M,k", [(7, 384, 10), (5, 512, 16), (3, 1000, 32), (4, 4096, 32), (2, 24576, 32),
-                                    (3, 131072, 192), (2, 2051, 7), (2, 6000, 1500), (2, 300, 300), (1, 262144, 768)])
+                                    (3, 131072, 192), (2, 2051, 7), (2, 6000, 1500), (2, 300, 300), (1, 262144, 768),
+                                    (2, 131072, 2048), (2, 40000, 4096), (1, 20000, 5000), (2, 262144, 1500)])
 def test_topk_random(device, dtype, N, M, k):
     from sparsify_amd import ops
     torch.manual_seed(M + k)
@@ -138,7 +139,8 @@ def test_topk_ties_and_degenerate_rows(device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,k,frac", [(4096, 24, 0.33), (4096, 2048, 0.33), (24576, 384, 0.1), (512, 100, 0.1)])
+@pytest.mark.parametrize("M,k,frac", [(4096, 24, 0.33), (4096, 2048, 0.33), (24576, 384, 0.1), (512, 100, 0.1),
+                                      (131072, 2048, 0.1), (131072, 2048, 0.01)])
 def test_topk_masked_auxk(device, dtype, M, k, frac):
     """where(dead_mask, pre, -inf).topk(k_aux) -- sparse_coder.py:240-243."""
     from sparsify_amd import ops
@@ -263,7 +265,7 @@ def test_latent_segments_bit_exact(device, N, k, M):
                                       (128, 16, 512, 2048), (64, 48, 1024, 4096), (40, 8, 64, 8200)])
 @pytest.mark.parametrize("rdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("variant", ["full", "sliced"])
+@pytest.mark.parametrize("variant", ["full", "sliced", "wide"])
 def test_segmented_weight_grad(device, monkeypatch, N, k, M, D, rdtype, cdtype, variant):
     from sparsify_amd import ops
     monkeypatch.setenv("SPHIP_WGRAD", variant)     # kernel used when no dcoeff is requested
