@@ -74,7 +74,7 @@ __device__ __forceinline__ unsigned block_count(unsigned c, unsigned* part, int 
 }
 
 template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ pre,
+__global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict__ pre,
                                                           const uint8_t* __restrict__ keep,
                                                           const T* __restrict__ tile_max, int M,
                                                           int k, T* __restrict__ vals,
