@@ -75,8 +75,17 @@ __global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict_
                                                         float scale, float* __restrict__ out) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= D) return;
+    // 16 loads in flight, added in chunk order (same sum as the plain loop)
     float s = 0.f;
-    for (int r = 0; r < nchunks; ++r) s += partial[(int64_t)r * D + col];
+    int r = 0;
+    for (; r + 16 <= nchunks; r += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(r + u) * D + col];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; r < nchunks; ++r) s += partial[(int64_t)r * D + col];
     out[col] = s * scale;
 }
 
