@@ -6,8 +6,11 @@ activations of a frozen model while it runs, like the reference's `Trainer(cfg, 
 The language model itself is outside the hot path: it is whatever torch module the caller
 brings (its forward runs through torch / rocBLAS); this file only resolves hookpoints, captures
 each hooked module's (input, output) as it is produced and hands it to the HIP train step of
-`Trainer.train_on_activations`, then runs the step tail. Only the local reconstruction loss
-("fvu") is supported; the end-to-end "ce"/"kl" losses need the model's backward (8f rank 3)."""
+`Trainer.train_on_activations`, then runs the step tail. With loss_fn "fvu" every coder is
+trained on its local reconstruction loss inside the hook; with "ce" / "kl" (8f rank 3,
+trainer.py:318-331, 425-430, 486-500) the hook splices the reconstruction into the model, the
+model's own loss is back-propagated through the frozen model into the coders, and the encoder's
+grad-input path (fused_encoder.py:58-64) is exercised."""
 from __future__ import annotations
 
 from fnmatch import fnmatchcase
@@ -100,8 +103,10 @@ class ModelTrainer(Trainer):
     a (num_sequences, S) LongTensor."""
 
     def __init__(self, cfg: TrainConfig, dataset, model: nn.Module):
-        if cfg.loss_fn != "fvu":
-            raise NotImplementedError(f"loss_fn={cfg.loss_fn!r}: only the local 'fvu' loss is on the HIP path")
+        if cfg.loss_fn not in ("fvu", "ce", "kl"):
+            raise ValueError(f"Unknown loss function '{cfg.loss_fn}'")
+        if cfg.loss_fn != "fvu" and (len(cfg.init_seeds) > 1 or cfg.distribute_modules):
+            raise ValueError("end-to-end losses need one coder per hookpoint on every rank")
         self.model = model
         self.dataset = dataset
         points = resolve_hookpoints(model, cfg)
@@ -130,20 +135,49 @@ class ModelTrainer(Trainer):
 
     def fit(self):
         self.model.requires_grad_(False)                          # trainer.py:242
+        cfg = self.cfg
+        e2e = cfg.loss_fn in ("ce", "kl")
         base = _base(self.model)
-        name_to_module = {name: base.get_submodule(name) for name in self.cfg.hookpoints}
+        batches = self._batches()
+        first = None
+        if cfg.loss_fn == "ce":
+            # trainer.py:318-331: report the clean loss; end-to-end transcoders replace the modules
+            first = next(batches, None)
+            if first is not None:
+                with torch.no_grad():
+                    x0 = first.to(self.device)
+                    self.clean_loss = float(self.maybe_all_reduce(self.model(x0, labels=x0).loss.detach().clone()))
+            if cfg.sae.transcode:
+                for point in cfg.hookpoints:
+                    set_submodule(base, point, nn.Identity())
+        name_to_module = {name: base.get_submodule(name) for name in cfg.hookpoints}
         module_to_name = {v: k for k, v in name_to_module.items()}
         k = self.get_current_k()
         for sae in self.saes.values():
             sae.cfg.k = k
         state = {"mask": None, "tokens": 0}
+        acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
+        denom = acc_steps * cfg.wandb_log_frequency
 
         def hook(module: nn.Module, inputs, outputs):             # trainer.py:340-447
+            aux_out = None
             if isinstance(inputs, tuple):
                 inputs = inputs[0]
             if isinstance(outputs, tuple):
-                outputs = outputs[0]
+                outputs, *aux_out = outputs
             hookpoint = module_to_name[module]
+            if e2e:
+                out_shape = outputs.shape
+                out, n = self.train_on_activations(hookpoint, inputs, outputs, state["mask"], e2e=True)
+                state["tokens"] = max(state["tokens"], n)
+                # trainer.py:425-430: the coder's output replaces the module's on the trained tokens
+                if state["mask"] is None:
+                    output = out.sae_out.type_as(outputs)
+                else:
+                    output = outputs.detach().flatten(0, 1).clone()
+                    output[state["mask"].reshape(-1)] = out.sae_out.type_as(output)
+                output = output.reshape(out_shape)
+                return (output, *aux_out) if aux_out is not None else output
             names = self._names_for(hookpoint) or [hookpoint]     # non-owners still join the gathers
             with torch.enable_grad():
                 for name in names:
@@ -151,21 +185,47 @@ class ModelTrainer(Trainer):
                     if res is not None:
                         state["tokens"] = max(state["tokens"], res[1])
 
-        for x in self._batches():
+        def all_batches():
+            if first is not None:
+                yield first
+            yield from batches
+
+        for x in all_batches():
             x = x.to(self.device)
             mask = torch.isin(x, self.exclude_tokens, invert=True)    # trainer.py:455
             state["mask"], state["tokens"] = (None if bool(mask.all()) else mask), 0
+            clean_probs = None
+            if cfg.loss_fn == "kl":                                   # trainer.py:474-479
+                with torch.no_grad():
+                    clean_probs = self.model(x).logits.softmax(dim=-1)
             handles = [mod.register_forward_hook(hook) for mod in name_to_module.values()]
             try:
-                with torch.no_grad():
-                    self.model(x)
+                if cfg.loss_fn == "fvu":
+                    with torch.no_grad():
+                        self.model(x)
+                elif cfg.loss_fn == "ce":                             # trainer.py:487-493
+                    ce = self.model(x, labels=x).loss
+                    ce.div(acc_steps).backward()
+                    self._metrics["ce_loss"] += ce.detach() / denom           # averaged over ranks when flushed
+                else:                                                 # trainer.py:494-500
+                    dirty_lps = self.model(x).logits.log_softmax(dim=-1)
+                    kl = -torch.sum(clean_probs * dirty_lps, dim=-1).mean()
+                    kl.div(acc_steps).backward()
+                    self._metrics["kl_loss"] += kl.detach() / denom
             finally:
                 for h in handles:
                     h.remove()
             n_step = state["tokens"]
-            if self.cfg.distribute_modules and n_step == 0:
+            if cfg.distribute_modules and n_step == 0:
                 import torch.distributed as dist
                 n_step = int(mask.sum()) * (dist.get_world_size() if dist.is_initialized() else 1)
             self.num_tokens_in_step += n_step
             self.step_tail()
         self.save()
+
+
+def set_submodule(model: nn.Module, submodule_path: str, new_submodule: nn.Module):
+    """utils.py:64-78: replace a submodule by its dotted path."""
+    parent_path, _, last = submodule_path.rpartition(".")
+    parent = model.get_submodule(parent_path) if parent_path else model
+    setattr(parent, last, new_submodule)

@@ -217,7 +217,10 @@ class Trainer:
             self._reducer.finish()
 
     # ------------------------------------------------------------------ the hook body (trainer.py:340-447)
-    def train_on_activations(self, name: str, inputs: Tensor | None, outputs: Tensor, mask: Tensor | None = None):
+    def train_on_activations(self, name: str, inputs: Tensor | None, outputs: Tensor, mask: Tensor | None = None,
+                             e2e: bool = False):
+        """e2e=True (loss_fn 'ce' / 'kl', trainer.py:425-430): forward and bookkeeping only; the
+        caller splices out.sae_out into the model and runs the backward itself."""
         cfg = self.cfg
         hook_name = name.partition("/")[0]
 
@@ -266,6 +269,9 @@ class Trainer:
 
         ops.mark_fired_(self.did_fire[name], out.latent_indices.reshape(-1))      # trainer.py:422
         self.maybe_all_reduce(self.did_fire[name], "max")
+
+        if e2e:
+            return out, n_tokens
 
         denom = cfg.grad_acc_steps * cfg.micro_acc_steps * cfg.wandb_log_frequency
         self._metrics[f"fvu/{name}"] += out.fvu.detach() / denom

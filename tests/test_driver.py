@@ -102,3 +102,84 @@ def test_model_trainer_equals_trainer_on_captured_activations(device, transcode)
     assert torch.equal(mt.num_tokens_since_fired[f"{points[0]}/seed0"], base.num_tokens_since_fired[f"{points[0]}/seed0"])
     assert fvus[-1] < fvus[0]
     assert mt.last_logged[f"fvu/{points[0]}/seed0"] == fvus[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_fn", ["ce", "kl"])
+def test_end_to_end_loss_gradients_match_torch_autograd(device, loss_fn):
+    """loss_fn 'ce' / 'kl' (trainer.py:425-430, 486-500): the model's loss is back-propagated through
+    the spliced reconstructions into the coders, including the encoder's grad-input path for the
+    second hookpoint. Checked against torch autograd on a plain-torch restatement of the coder
+    (same bf16 autocast, same selected latents)."""
+    import torch.nn.functional as F
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.driver import ModelTrainer
+    model = tiny_lm().cuda()
+    S, B, vocab = 32, 8, 128
+    data = torch.randint(0, vocab, (B, S), generator=torch.Generator().manual_seed(3))
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=512, k=8), optimizer="signsgd", lr=1e-3, loss_fn=loss_fn,
+                      hookpoints=["layers.0", "layers.2"], batch_size=B, grad_acc_steps=2,      # no optimizer step yet
+                      save_dir="", save_every=10**9, wandb_log_frequency=1)
+    mt = ModelTrainer(cfg, data, model)
+    init = {n: {k: v.detach().clone() for k, v in sae.state_dict().items()} for n, sae in mt.saes.items()}
+    picked = {}
+    orig = mt.train_on_activations
+
+    def spy(name, inputs, outputs, mask=None, e2e=False):
+        out, n = orig(name, inputs, outputs, mask, e2e=e2e)
+        picked[name] = out.latent_indices.detach().clone()
+        return out, n
+
+    mt.train_on_activations = spy
+    mt.fit()
+    assert mt.global_step == 1 and set(picked) == {"layers.0", "layers.2"}
+
+    # ---- plain-torch restatement, driven by autograd
+    x = data.cuda()
+    ref = {}
+    for name, sd in init.items():
+        ref[name] = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        # step-0 initialisation the hook applied before the forward (trainer.py:403-408)
+    acts0 = {}
+
+    def mk(name):
+        def hook(mod, inputs, outputs):
+            h, *aux = outputs if isinstance(outputs, tuple) else (outputs,)
+            flat = h.flatten(0, 1)
+            P = ref[name]
+            if name not in acts0:
+                acts0[name] = True
+                with torch.no_grad():
+                    P["b_dec"].copy_(flat.detach().float().mean(0))
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pre = F.relu(F.linear(flat - P["b_dec"], P["encoder.weight"], P["encoder.bias"]))
+                top = pre.gather(1, picked[name])
+            rec = (P["W_dec"][picked[name]] * top.float().unsqueeze(-1)).sum(1) + P["b_dec"]
+            out = rec.type_as(h).reshape(h.shape)
+            return (out, *aux) if isinstance(outputs, tuple) else out
+        return hook
+
+    hs = [model.base_model.get_submodule(n).register_forward_hook(mk(n)) for n in ref]
+    try:
+        if loss_fn == "ce":
+            loss = model(x, labels=x).loss
+        else:
+            for h in hs:
+                h.remove()
+            with torch.no_grad():
+                clean = model(x).logits.softmax(-1)
+            hs = [model.base_model.get_submodule(n).register_forward_hook(mk(n)) for n in ref]
+            loss = -torch.sum(clean * model(x).logits.log_softmax(-1), dim=-1).mean()
+        (loss / 2).backward()
+    finally:
+        for h in hs:
+            h.remove()
+    for name, sae in mt.saes.items():
+        got = dict(sae.named_parameters())
+        for pname, p_ref in ref[name].items():
+            g_ref, g_got = p_ref.grad, got[pname].grad
+            assert g_got is not None and g_ref is not None, f"{name}.{pname}"
+            cos = F.cosine_similarity(g_got.flatten().double(), g_ref.flatten().double(), dim=0)
+            rel = (g_got.double() - g_ref.double()).norm() / g_ref.double().norm()
+            # bf16 autocast on both sides, different accumulation orders
+            assert cos > 0.999 and rel < 4e-2, f"{name}.{pname}: cos {cos:.5f} rel {rel:.3e}"
