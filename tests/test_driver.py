@@ -183,3 +183,21 @@ def test_end_to_end_loss_gradients_match_torch_autograd(device, loss_fn):
             rel = (g_got.double() - g_ref.double()).norm() / g_ref.double().norm()
             # bf16 autocast on both sides, different accumulation orders
             assert cos > 0.999 and rel < 4e-2, f"{name}.{pname}: cos {cos:.5f} rel {rel:.3e}"
+
+
+def test_memmap_dataset(tmp_path):
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from sparsify_amd.data import MemmapDataset
+    toks = (np.arange(10 * 16 + 5) % 50000).astype(np.uint16)       # 5 trailing tokens do not fill a row
+    path = tmp_path / "tokens.bin"
+    toks.tofile(path)
+    ds = MemmapDataset(str(path), ctx_len=16)
+    assert len(ds) == 10 and ds[3]["input_ids"].dtype == torch.int64
+    assert torch.equal(ds[3]["input_ids"], torch.arange(48, 64))
+    assert len(MemmapDataset(str(path), 16, max_examples=4)) == 4
+    assert torch.equal(ds.select(range(2, 5))[0]["input_ids"], ds[2]["input_ids"]) and len(ds.select(range(2, 5))) == 3
+    parts = [ds.shard(3, i) for i in range(3)]
+    assert [len(p) for p in parts] == [4, 3, 3] and torch.equal(parts[1][0]["input_ids"], ds[4]["input_ids"])
+    batch = next(iter(DataLoader(ds, batch_size=4)))
+    assert batch["input_ids"].shape == (4, 16)
