@@ -201,6 +201,8 @@ def main():
             "hbm_kernels": {
                 "decode_gather_GBs": gather_bytes / (dec["total_ms"] / dec["calls"] * 1e-3) / 1e9,
                 "segmented_wgrad_GBs": 2 * N * k * D * 4 / (wg["total_ms"] / args.steps * 1e-3) / 1e9,
+                # M*2 B read per token (the kernel itself reads ~1/4 of that)
+                "topk_GBs": N * M * 2 / (kern["sphip_topk"]["total_ms"] / args.steps * 1e-3) / 1e9,
                 "peak_GBs": HBM_PEAK_GBS,
             },
         }
