@@ -182,6 +182,20 @@ int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D
 
 /* ---------------------------------------------------------------- dead-latent bookkeeping */
 
+/* ScheduleFreeWrapper(SignSGD, momentum = beta).step() -- the reference's default optimizer
+ * "signum", trainer.py:146-162 -- in one pass over (p, z, g): p holds y (where gradients are
+ * taken), z the SignSGD iterate; x = lerp(y, z, 1 - 1/beta); z -= lr sign(g);
+ * x = lerp(x, z, c); y = lerp(x, z, 1 - beta), lerp as torch.lerp. The schedule-free package is
+ * not part of the reference tree (parity unpinned; the host class schedule_free.py states the
+ * algorithm it restates). The decoder form first projects g on the orthogonal complement of
+ * the row (sparse_coder.py:281-295) and, with renorm != 0, normalises the new row
+ * (sparse_coder.py:273-279); D <= 4096. */
+int sphip_schedulefree_signsgd_step(float* p, float* z, const float* g, int64_t n, float lr,
+                                    float beta, float c, void* bf16_shadow, void* stream);
+int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M,
+                                            int64_t D, float lr, float beta, float c, int renorm,
+                                            void* stream);
+
 /* Sign exchange for data-parallel SignSGD (DDP gradient exchange, trainer.py:457-468, done as
  * reduce-scatter of the fp32 gradients + all-gather of 1-byte signs instead of an all-reduce:
  * SignSGD.step, sign_sgd.py:23, only needs sign(mean gradient); 5/8 of the bytes on the wire).

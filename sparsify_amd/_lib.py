@@ -47,6 +47,8 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_remove_parallel_grad": (_I, [_P, _P, _L, _L, _P]),
     "sphip_signsgd_step": (_I, [_P, _P, _L, _F, _P, _P]),
     "sphip_decoder_project_signsgd": (_I, [_P, _P, _L, _L, _F, _I, _P]),
+    "sphip_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
+    "sphip_decoder_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),
     "sphip_apply_signs": (_I, [_P, _P, _L, _F, _P, _P]),

@@ -348,6 +348,112 @@ __global__ __launch_bounds__(256) void apply_signs_norm_kernel(float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Schedule-free SignSGD (the reference's default optimizer "signum":
+// ScheduleFreeWrapper(SignSGD, momentum), trainer.py:146-162) in one pass. Per element, with
+// y the parameter (where gradients are taken), z the base iterate, x the running average:
+//     x  = lerp(y, z, 1 - 1/beta)          (undo y = beta x + (1 - beta) z)
+//     z' = z - lr * sign(g)                (SignSGD on z, sign_sgd.py:23)
+//     x' = lerp(x, z', c)                  (c = w_t / sum w)
+//     y' = lerp(x', z', 1 - beta)
+// lerp(a, b, w) = |w| < 0.5 ? a + w (b - a) : b - (b - a)(1 - w), as torch.lerp.
+__device__ __forceinline__ float lerpf(float a, float b, float w) {
+    const float d = b - a;
+    return fabsf(w) < 0.5f ? fmaf(w, d, a) : fmaf(-d, 1.f - w, b);
+}
+__device__ __forceinline__ void sf_update(float& y, float& z, float sgn, float lr, float w_undo, float c, float w_y) {
+    const float x = lerpf(y, z, w_undo);
+    z = z - lr * sgn;
+    const float x2 = lerpf(x, z, c);
+    y = lerpf(x2, z, w_y);
+}
+
+__global__ __launch_bounds__(256) void sf_signsgd_kernel(float* __restrict__ p, float* __restrict__ zb,
+                                                         const float* __restrict__ g, int64_t n, float lr,
+                                                         float w_undo, float c, float w_y, bf16_t* __restrict__ shadow) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 y = *reinterpret_cast<const float4*>(p + i * 4);
+        float4 z = *reinterpret_cast<const float4*>(zb + i * 4);
+        const float4 a = *reinterpret_cast<const float4*>(g + i * 4);
+        sf_update(y.x, z.x, (float)sgn(a.x), lr, w_undo, c, w_y);
+        sf_update(y.y, z.y, (float)sgn(a.y), lr, w_undo, c, w_y);
+        sf_update(y.z, z.z, (float)sgn(a.z), lr, w_undo, c, w_y);
+        sf_update(y.w, z.w, (float)sgn(a.w), lr, w_undo, c, w_y);
+        *reinterpret_cast<float4*>(p + i * 4) = y;
+        *reinterpret_cast<float4*>(zb + i * 4) = z;
+        if (shadow != nullptr) *reinterpret_cast<uint2*>(shadow + i * 4) = pack_bf16x4(y);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float y = p[i], z = zb[i];
+        sf_update(y, z, (float)sgn(g[i]), lr, w_undo, c, w_y);
+        p[i] = y;
+        zb[i] = z;
+        if (shadow != nullptr) shadow[i] = f32_to_bf16(y);
+    }
+}
+
+// Decoder rows: the gradient is first projected on the row's orthogonal complement
+// (sparse_coder.py:281-295, W = y), and with renorm the new y is normalised in the same pass
+// (the set_decoder_norm_to_unit_norm that opens the next step). Row-resident, D <= 1024 R.
+template <int R>
+__global__ __launch_bounds__(256) void sf_decoder_kernel(float* __restrict__ W, float* __restrict__ Z,
+                                                         const float* __restrict__ G, int D, float lr, float w_undo,
+                                                         float c, float w_y, int renorm, float eps) {
+    __shared__ float red[16];
+    float* w = W + (int64_t)blockIdx.x * D;
+    float* zr = Z + (int64_t)blockIdx.x * D;
+    const float* g = G + (int64_t)blockIdx.x * D;
+    float4 y[R], z[R], a[R];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        const bool in = col < D;
+        y[i] = in ? *reinterpret_cast<const float4*>(w + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        z[i] = in ? *reinterpret_cast<const float4*>(zr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[i] = in ? *reinterpret_cast<const float4*>(g + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        acc = fmaf(a[i].x, y[i].x, acc); acc = fmaf(a[i].y, y[i].y, acc);
+        acc = fmaf(a[i].z, y[i].z, acc); acc = fmaf(a[i].w, y[i].w, acc);
+    }
+    const float par = block_sum(acc, red);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        const float4 pr = make_float4(a[i].x - par * y[i].x, a[i].y - par * y[i].y, a[i].z - par * y[i].z,
+                                      a[i].w - par * y[i].w);
+        sf_update(y[i].x, z[i].x, (float)sgn(pr.x), lr, w_undo, c, w_y);
+        sf_update(y[i].y, z[i].y, (float)sgn(pr.y), lr, w_undo, c, w_y);
+        sf_update(y[i].z, z[i].z, (float)sgn(pr.z), lr, w_undo, c, w_y);
+        sf_update(y[i].w, z[i].w, (float)sgn(pr.w), lr, w_undo, c, w_y);
+        if (col < D) {
+            ss = fmaf(y[i].x, y[i].x, ss); ss = fmaf(y[i].y, y[i].y, ss);
+            ss = fmaf(y[i].z, y[i].z, ss); ss = fmaf(y[i].w, y[i].w, ss);
+        }
+    }
+    if (renorm) {
+        const float denom = sqrtf(block_sum(ss, red)) + eps;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            y[i].x /= denom; y[i].y /= denom; y[i].z /= denom; y[i].w /= denom;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        if (col < D) {
+            *reinterpret_cast<float4*>(w + col) = y[i];
+            *reinterpret_cast<float4*>(zr + col) = z[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mark_fired_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t M,
                                                          uint8_t* __restrict__ fired) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -543,6 +649,38 @@ extern "C" int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t 
     const int st = sphip_apply_signs(W, signs, M * D, lr, nullptr, stream);
     if (st != SPHIP_OK || !renorm) return st;
     return sphip_unit_norm_rows(W, M, D, stream);
+}
+
+extern "C" int sphip_schedulefree_signsgd_step(float* p, float* z, const float* g, int64_t n, float lr, float beta,
+                                               float c, void* bf16_shadow, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(p && z && g, SPHIP_EINVAL, "schedulefree_signsgd_step: null pointer");
+    SPHIP_REQUIRE(n > 0 && beta > 0.f && beta <= 1.f, SPHIP_EINVAL, "schedulefree_signsgd_step: bad n / beta");
+    SPHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)g & 15) == 0 &&
+                      ((uintptr_t)bf16_shadow & 7) == 0,
+                  SPHIP_EINVAL, "schedulefree_signsgd_step: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(sf_signsgd_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, z, g, n, lr,
+                       1.f - 1.f / beta, c, 1.f - beta, (bf16_t*)bf16_shadow);
+    SPHIP_CHECK_LAUNCH("schedulefree_signsgd_step");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr,
+                                                       float beta, float c, int renorm, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && Z && G, SPHIP_EINVAL, "decoder_schedulefree_signsgd_step: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
+                  "decoder_schedulefree_signsgd_step: bad shape / beta");
+    SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 && ((uintptr_t)G & 15) == 0,
+                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_signsgd_step: needs D %% 4 == 0, D <= 4096, 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)M), block(256);
+    const float wu = 1.f - 1.f / beta, wy = 1.f - beta;
+    if (D <= 1024) hipLaunchKernelGGL((sf_decoder_kernel<1>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else hipLaunchKernelGGL((sf_decoder_kernel<4>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
+    return SPHIP_OK;
 }
 
 extern "C" int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire, void* stream) {

@@ -363,6 +363,36 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
     return p
 
 
+def schedulefree_signsgd_step_(p: Tensor, z: Tensor, g: Tensor, lr: float, beta: float, c: float,
+                                bf16_shadow: Tensor | None = None) -> Tensor:
+    """One pass of ScheduleFreeWrapper(SignSGD).step() over (p = y, z, g); see sparsify_hip.h."""
+    _req(p, "param", torch.float32)
+    _req(z, "z", torch.float32)
+    _req(g, "grad", torch.float32)
+    if z.shape != p.shape or g.shape != p.shape:
+        raise ValueError("schedulefree_signsgd_step: shape mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    check(_lib.load().sphip_schedulefree_signsgd_step(p.data_ptr(), z.data_ptr(), g.data_ptr(), p.numel(), float(lr),
+                                                     float(beta), float(c), _ptr(bf16_shadow), _stream(p)),
+          "sphip_schedulefree_signsgd_step")
+    return p
+
+
+def decoder_schedulefree_signsgd_step_(W: Tensor, Z: Tensor, G: Tensor, lr: float, beta: float, c: float,
+                                        renorm: bool = False) -> Tensor:
+    """The same for decoder rows: projected gradient, step, optional re-normalisation of y."""
+    _req(W, "W_dec", torch.float32, 2)
+    _req(Z, "z", torch.float32, 2)
+    _req(G, "W_dec.grad", torch.float32, 2)
+    if Z.shape != W.shape or G.shape != W.shape:
+        raise ValueError("decoder_schedulefree_signsgd_step: shape mismatch")
+    check(_lib.load().sphip_decoder_schedulefree_signsgd_step(W.data_ptr(), Z.data_ptr(), G.data_ptr(), W.shape[0],
+                                                             W.shape[1], float(lr), float(beta), float(c), int(renorm),
+                                                             _stream(W)), "sphip_decoder_schedulefree_signsgd_step")
+    return W
+
+
 # ---- sign exchange (data-parallel SignSGD, parallel.SignExchange)
 def sign_i8(g: Tensor, out: Tensor | None = None) -> Tensor:
     """int8 sign(g) (-1 / 0 / +1)."""

@@ -13,6 +13,11 @@ algorithm (Defazio et al., "The Road Less Scheduled", 2024):
            x <- (1 - c) x + c z   with  c = w / sum(w),  w = lr_max ** weight_lr_power,
            parameter <- y = beta x + (1 - beta) z
     eval(): parameter <- x          train(): parameter <- y
+
+With the SignSGD base of this package on HIP tensors the whole step is ONE kernel per parameter
+(sphip_schedulefree_signsgd_step, for decoder groups with the projected gradient and the
+re-normalisation fused in: sphip_decoder_schedulefree_signsgd_step) instead of the ~10
+full-tensor passes of the generic path below; both paths implement the same arithmetic.
 """
 from __future__ import annotations
 
@@ -70,10 +75,88 @@ class ScheduleFreeWrapper:
                         p.lerp_(st["z"], 1 - self.momentum)          # x -> y
             self.train_mode = True
 
+    @property
+    def renormalised(self):
+        return getattr(self.base, "renormalised", None)
+
+    def _weights(self, group) -> float:
+        lr = group["lr"] * group.get("d", 1.0)
+        group["lr_max"] = max(lr, group["lr_max"])
+        weight = ((group["k"] + 1) ** self.r) * (group["lr_max"] ** self.weight_lr_power)
+        group["weight_sum"] += weight
+        return weight / group["weight_sum"] if group["weight_sum"] > 0 else 0.0
+
+    def _fusable(self) -> bool:
+        from .sign_sgd import SignSGD
+        if not isinstance(self.base, SignSGD) or getattr(self.base, "exchange_signs", False):
+            return False
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    return False
+                if group.get("project_rows", False) and (p.ndim != 2 or p.shape[1] % 4 or p.shape[1] > 4096):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def _fused_step(self):
+        from . import ops
+        from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
+        for group in self.param_groups:
+            c = self._weights(group)
+            project, renorm = group.get("project_rows", False), group.get("renorm_rows", False)
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if "z" not in st:
+                    st["z"] = p.detach().clone(memory_format=torch.preserve_format)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if project:
+                    ops.decoder_schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, renorm)
+                    if renorm:
+                        self.base.renormalised.add(id(p))
+                else:
+                    shadow = peek_bf16_shadow(p)
+                    ops.schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, shadow)
+                    if shadow is not None:
+                        register_bf16_shadow(p, shadow)
+                torch.autograd.graph.increment_version(p)
+            group["k"] += 1
+
     @torch.no_grad()
     def step(self, closure=None):
         if not self.train_mode:
             raise RuntimeError("call .train() on the schedule-free optimizer before stepping")
+        if self._fusable():
+            return self._fused_step()
+        # generic path; decoder groups: project the gradient w.r.t. the parameter (= y) first and
+        # keep the base optimizer from projecting again w.r.t. z
+        flagged = [g for g in self.param_groups if g.get("project_rows", False)]
+        if flagged:
+            from . import ops
+            for group in flagged:
+                for p in group["params"]:
+                    if p.grad is not None:
+                        ops.remove_parallel_grad_(p.grad, p.data)
+                group["project_rows"] = False
+        try:
+            self._generic_step()
+        finally:
+            for group in flagged:
+                group["project_rows"] = True
+        for group in flagged:
+            if group.get("renorm_rows", False):
+                from . import ops
+                for p in group["params"]:
+                    if p.grad is not None:
+                        ops.unit_norm_rows_(p.data)
+                        self.base.renormalised.add(id(p))
+
+    @torch.no_grad()
+    def _generic_step(self):
         swapped = []
         for group in self.param_groups:
             for p in group["params"]:
@@ -91,11 +174,7 @@ class ScheduleFreeWrapper:
                 swapped.append((group, p))
         self.base.step()
         for group in self.param_groups:
-            lr = group["lr"] * group.get("d", 1.0)
-            group["lr_max"] = max(lr, group["lr_max"])
-            weight = ((group["k"] + 1) ** self.r) * (group["lr_max"] ** self.weight_lr_power)
-            group["weight_sum"] += weight
-            c = weight / group["weight_sum"] if group["weight_sum"] > 0 else 0.0
+            c = self._weights(group)
             for p in group["params"]:
                 if p.grad is None:
                     continue

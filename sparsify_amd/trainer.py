@@ -149,14 +149,11 @@ class Trainer:
                     _linear_warmup_decay(self.optimizers[0], 0, num_batches),
                     _linear_warmup_decay(self.optimizers[1], cfg.lr_warmup_steps, num_batches),
                 ]
-            case "signum":
-                pgs = groups(lambda s: 5e-3 / (s.num_latents / (2**14)) ** 0.5)
-                opt = ScheduleFreeWrapper(SignSGD(pgs), momentum=0.95)
-                opt.train()
-                self.optimizers = [opt]
-            case "signsgd":
-                # plain SignSGD (sign_sgd.py) with the "signum" learning-rate rule; the fused
-                # projected-gradient + sign step handles W_dec in one pass
+            case "signum" | "signsgd":
+                # SignSGD (sign_sgd.py) with the reference's learning-rate rule (trainer.py:152);
+                # decoder matrices get a group of their own whose step fuses the projected
+                # gradient (trainer.py:513-515) and the re-normalisation (trainer.py:406-408).
+                # "signum" (the reference's default) wraps it schedule-free, "signsgd" is plain.
                 pgs = []
                 for sae in self.saes.values():
                     lr = cfg.lr or 5e-3 / (sae.num_latents / (2**14)) ** 0.5
@@ -165,7 +162,12 @@ class Trainer:
                     if dec:
                         pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
-                self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs)]
+                if cfg.optimizer == "signum":
+                    opt = ScheduleFreeWrapper(SignSGD(pgs), momentum=0.95)
+                    opt.train()
+                    self.optimizers = [opt]
+                else:
+                    self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs)]
                 self._fused_projection = project
             case other:
                 raise ValueError(f"Unknown optimizer '{other}'")

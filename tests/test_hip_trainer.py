@@ -119,3 +119,45 @@ def test_trainer_grad_accumulation_and_k_decay(device):
     assert stepped == [False, True] * 4                                 # divmod(global_step+1, 2), trainer.py:511
     assert ks[0] == min(M, 10 * D) and ks[-1] == k and ks == sorted(ks, reverse=True)   # trainer.py:229-235
     assert not torch.equal(tr.saes["h0"].encoder.weight, w0)
+
+
+@pytest.mark.parametrize("D", [64, 1024, 4096])
+def test_schedulefree_fused_step_equals_generic_path(device, monkeypatch, D):
+    """ScheduleFreeWrapper(SignSGD): the one-kernel step (plain and decoder groups with projection
+    + re-normalisation) against the generic multi-pass path of the same class."""
+    from sparsify_amd.schedule_free import ScheduleFreeWrapper
+    from sparsify_amd.sign_sgd import SignSGD
+    M, steps = 96, 6
+    torch.manual_seed(D)
+    W0 = O.unit_norm_rows(torch.randn(M, D))
+    E0, b0 = torch.randn(M, D), torch.randn(M)
+    grads = [(torch.randn(M, D), torch.randn(M, D), torch.randn(M)) for _ in range(steps)]
+
+    def run(fused: bool):
+        Wd, We, b = (torch.nn.Parameter(t.clone().cuda()) for t in (W0, E0, b0))
+        opt = ScheduleFreeWrapper(SignSGD([dict(params=[Wd], lr=3e-3, project_rows=True, renorm_rows=True),
+                                           dict(params=[We, b], lr=3e-3)]), momentum=0.95)
+        opt.train()
+        if not fused:
+            monkeypatch.setattr(ScheduleFreeWrapper, "_fusable", lambda self: False)
+        else:
+            monkeypatch.undo()
+            assert opt._fusable() or steps == 0 or Wd.grad is None
+        for gd, ge, gb in grads:
+            Wd.grad, We.grad, b.grad = gd.clone().cuda(), ge.clone().cuda(), gb.clone().cuda()
+            opt.step()
+            assert id(Wd) in opt.renormalised
+            opt.renormalised.discard(id(Wd))
+        z = [opt.state[p]["z"].cpu() for p in (Wd, We, b)]
+        opt.eval()
+        x = [p.detach().cpu().clone() for p in (Wd, We, b)]
+        return x, z
+
+    xf, zf = run(True)
+    xg, zg = run(False)
+    for a, c in zip(xf[1:] + zf[1:], xg[1:] + zg[1:]):
+        torch.testing.assert_close(a, c, rtol=2e-6, atol=2e-7)
+    # decoder: sign() of a ~0 projected component may differ between the two reduction orders
+    for a, c in ((xf[0], xg[0]), (zf[0], zg[0])):
+        bad = (a - c).abs() > 1e-5
+        assert bad.float().mean() < 2e-3
