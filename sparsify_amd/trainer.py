@@ -134,7 +134,7 @@ class Trainer:
         match cfg.optimizer:
             case "adam":
                 pgs = groups(lambda s: 2e-4 / (s.num_latents / (2**14)) ** 0.5)
-                adam = torch.optim.Adam(pgs)
+                adam = torch.optim.Adam(pgs, fused=self.device.type == "cuda")   # one multi-tensor kernel
                 self.optimizers = [adam]
                 self.lr_schedulers = [_linear_warmup_decay(adam, cfg.lr_warmup_steps, num_batches)]
             case "muon":
