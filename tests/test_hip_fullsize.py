@@ -1,0 +1,106 @@
+"""Size-independent properties at BASELINE.json's headline sizes (N = 16384 tokens, D = 4096,
+M = 131072 latents, k = 192), where the CPU oracle cannot run: the kernels that the training
+shapes select (256-tile GEMM with block maxima, block-maxima top-k, Infinity-Cache-sliced gather,
+wide-sliced and L2-sliced weight gradients, row-resident decoder step) are checked through
+identities that hold for any correct implementation."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, D, M, K = 16384, 4096, 131072, 192
+
+
+@pytest.fixture(scope="module")
+def state():
+    from sparsify_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = (torch.randn(N, D, device=dev, generator=g) + torch.randn(D, device=dev, generator=g)).to(torch.bfloat16)
+    W = (torch.rand(M, D, device=dev, generator=g) * 2 - 1) / D**0.5
+    b = torch.zeros(M, device=dev, dtype=torch.bfloat16)
+    Wb = W.to(torch.bfloat16)
+    pre, tmax = ops.encoder_preacts(x, Wb, b, want_tile_max=True)
+    vals, idx = ops.topk(pre, K, tile_max=tmax)
+    return dict(x=x, W=W, Wb=Wb, pre=pre, tmax=tmax, vals=vals, idx=idx, gen=g)
+
+
+def test_gemm_rows_against_fp64_and_block_maxima(state):
+    """Sampled rows of the 256-tile GEMM against an fp64 product of the same bf16 operands; the
+    block maxima are exactly the maxima of the stored pre-activations."""
+    rows = torch.tensor([0, 1, 255, 256, 8191, 16383], device="cuda")
+    ref = torch.relu(state["x"][rows].double() @ state["Wb"].double().T)
+    got = state["pre"][rows].double()
+    # one bf16 rounding of an fp32-accumulated sum of 4096 products
+    torch.testing.assert_close(got, ref, rtol=2**-7, atol=2e-3)
+    pm = state["pre"].view(N, M // 128, 128).amax(dim=2)                      # (N, T)
+    tm = state["tmax"].permute(0, 2, 1).reshape(N, M // 128)                  # [n//64, t, n%64] -> (N, T)
+    assert torch.equal(pm, tm)
+
+
+def test_topk_is_the_exact_selection(state):
+    """Every selected value is its row's entry at the selected index, indices are distinct, and the
+    k-th largest selected value is the row's k-th largest entry (torch.kthvalue as the checker)."""
+    pre, vals, idx = state["pre"], state["vals"], state["idx"]
+    assert torch.equal(pre.gather(1, idx), vals)
+    assert int((idx.sort(dim=1).values.diff(dim=1) == 0).sum()) == 0
+    kth = pre.float().kthvalue(M - K + 1, dim=1).values
+    assert torch.equal(vals.float().min(dim=1).values, kth)
+    # nothing outside the selection exceeds the k-th value
+    above = (pre.float() > kth[:, None]).sum(dim=1)
+    assert int(above.max()) <= K - 1
+    # the plain full-row kernel returns the same thing
+    from sparsify_amd import ops
+    v2, i2 = ops.topk(pre, K)
+    assert torch.equal(v2, vals) and torch.equal(i2, idx)
+
+
+def test_decode_is_linear_and_adjoint_to_the_weight_gradient(state):
+    """decode(a1 + a2) = decode(a1) + decode(a2); <g, decode(c)> = sum_e c_e dcoeff_e (the dot of
+    the W_dec gradient pass is the adjoint of the decode gather); sum_j gW[j, :] = sum_n (sum_s
+    c[n, s]) g[n, :] (checksum over all latents); the L2-sliced kernel writes the same gW."""
+    from sparsify_amd import ops
+    g, idx, W = state["gen"], state["idx"], state["W"]
+    a1 = torch.rand(N, K, device="cuda", generator=g)
+    a2 = torch.rand(N, K, device="cuda", generator=g)
+    y1, y2, y12 = (ops.gather_rows_weighted(idx, a, W) for a in (a1, a2, a1 + a2))
+    torch.testing.assert_close(y12, y1 + y2, rtol=2e-5, atol=2e-5)
+    grad = torch.randn(N, D, device="cuda", generator=g)
+    seg = ops.build_latent_segments(idx, M)
+    gW, _, dc = ops.segmented_weight_grad(seg, a1, grad, W, want_dcoeff=True)
+    lhs = (grad.double() * y1.double()).sum()
+    rhs = (a1.double() * dc.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float(lhs.abs() + rhs.abs()) + 1e-3
+    chk = gW.double().sum(dim=0)
+    ref = (a1.double().sum(dim=1, keepdim=True) * grad.double()).sum(dim=0)
+    # 131072 fp32-rounded rows per column sum
+    torch.testing.assert_close(chk, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    gW2, _, _ = ops.segmented_weight_grad(seg, a1, grad)                     # no dcoeff: L2-sliced kernel
+    assert torch.equal(gW, gW2)
+    # segments: a stable permutation of all entries, sorted by latent
+    perm = seg.perm.to(torch.int64)
+    assert torch.equal(perm.sort().values, torch.arange(N * K, device="cuda"))
+    lat = idx.reshape(-1)[perm]
+    assert bool((lat.diff() >= 0).all())
+    assert bool(((lat.diff() > 0) | (perm.diff() > 0)).all())
+
+
+def test_decoder_step_and_unit_norm_are_idempotent_where_they_should_be(state):
+    from sparsify_amd import ops
+    W = state["W"].clone()
+    ops.unit_norm_rows_(W)
+    torch.testing.assert_close(W.norm(dim=1), torch.ones(M, device="cuda"), rtol=1e-5, atol=0)
+    W2 = W.clone()
+    ops.unit_norm_rows_(W2)
+    torch.testing.assert_close(W2, W, rtol=0, atol=3e-7)                     # idempotent up to 1/(1 + eps)
+    G = torch.randn(M, D, device="cuda", generator=state["gen"])
+    Gp = G.clone()
+    ops.remove_parallel_grad_(Gp, W)
+    assert float((Gp * W).sum(dim=1).abs().max()) < 1e-3                     # projected rows are orthogonal
+    Gpp = Gp.clone()
+    ops.remove_parallel_grad_(Gpp, W)
+    torch.testing.assert_close(Gpp, Gp, rtol=0, atol=1e-5)                   # projecting twice changes nothing
+    Wa, Wb = W.clone(), W.clone()
+    ops.decoder_project_signsgd_(Wa, G, 1e-3, True)
+    ops.decoder_project_signsgd_(Wb, Gp, 1e-3, True)                         # same step from the projected gradient
+    assert float(((Wa - Wb).abs() > 1e-6).float().mean()) < 1e-3
