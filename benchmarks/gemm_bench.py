@@ -16,16 +16,20 @@ x = torch.randn(N, D, device=dev, generator=g).to(torch.bfloat16)
 W = (torch.randn(M, D, device=dev, generator=g) / 64).to(torch.bfloat16)
 b = torch.zeros(M, device=dev, dtype=torch.bfloat16)
 diags = sys.argv[1:] or ["0"]
-for dg in diags:
-    os.environ["SPHIP_GEMM_DIAG"] = dg
-    for _ in range(3):
+res = {dg: [] for dg in diags}
+for rnd in range(3):                      # interleaved rounds: variants share the device's state
+    for dg in diags:
+        os.environ["SPHIP_GEMM_DIAG"] = dg
         ops.encoder_preacts(x, W, b)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        ops.encoder_preacts(x, W, b)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"diag={dg} {ms:.3f} ms  {2.0 * N * D * M / ms / 1e9:.0f} TFLOP/s", flush=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.encoder_preacts(x, W, b)
+        e1.record()
+        torch.cuda.synchronize()
+        res[dg].append(e0.elapsed_time(e1) / 5)
+for dg, v in res.items():
+    v = sorted(v)
+    ms = v[len(v) // 2]
+    print(f"diag={dg} median {ms:.3f} ms (min {v[0]:.3f})  {2.0 * N * D * M / ms / 1e9:.0f} TFLOP/s", flush=True)

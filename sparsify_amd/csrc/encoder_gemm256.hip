@@ -185,7 +185,8 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
             seg_barrier();
             return;
         }
-        __builtin_amdgcn_s_setprio(1);
+        constexpr int VAR = DIAG >> 6;               // schedule variants (diagnostic builds)
+        if (VAR != 1) __builtin_amdgcn_s_setprio(VAR == 2 ? 3 : 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -196,7 +197,18 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                         __builtin_bit_cast(bf16x8_t, wf[mt][ks]), __builtin_bit_cast(bf16x8_t, xf[nt][ks]),
                         acc[mbase + mt][nt], 0, 0, 0);
                 const int j = ks * 4 + mt;
-                if (j < ndma) {
+                if (VAR == 3) {                      // DMA issue one group later
+                    if (j >= 1 && j - 1 < ndma) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma(j - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (VAR == 4) {               // two DMAs per group
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (2 * j < ndma) dma(2 * j);
+                    if (2 * j + 1 < ndma) dma(2 * j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (j < ndma) {
                     __builtin_amdgcn_sched_barrier(0);
                     dma(j);
                     __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                 // overlaps this wave's last MFMAs instead of idling the matrix pipe
                 if (j == 7 - EARLY) seg_barrier();
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (VAR != 1) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- prologue: K tile 0 completely plus X / W-lo of K tile 1; X(0), W-lo(0) retired
@@ -374,7 +386,9 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 // Diagnostic builds (make DIAG=1): SPHIP_GEMM_DIAG selects a kernel with parts of the loop
 // removed (bit 0: no DMA, 1: no MFMA, 2: no ds_read, 3: no epilogue store, 4: every tile reads
 // tile 0/1 of each operand, 5: per-segment cycle stamps written to the SPHIP_GEMM_DBG
-// buffer); benchmarks/gemm_bench.py and benchmarks/gemm_stamps.py drive them.
+// buffer; values 64 k select schedule variant k: 1 no s_setprio, 2 s_setprio 3, 3 DMA issue one
+// MFMA group later, 4 two DMAs per group -- measured 12.32 / 12.37 / 12.40 / 12.94 ms against
+// 12.40 ms for the shipped schedule); benchmarks/gemm_bench.py and gemm_stamps.py drive them.
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
@@ -423,6 +437,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
     else if (diag == 37) SPHIP_DIAG_LAUNCH(37)
     else if (diag == 22) SPHIP_DIAG_LAUNCH(22)
     else if (diag == 20) SPHIP_DIAG_LAUNCH(20)
+    else if (diag == 64) SPHIP_DIAG_LAUNCH(64)
+    else if (diag == 128) SPHIP_DIAG_LAUNCH(128)
+    else if (diag == 192) SPHIP_DIAG_LAUNCH(192)
+    else if (diag == 256) SPHIP_DIAG_LAUNCH(256)
     else
 #endif
     if (relu)
