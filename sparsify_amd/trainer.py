@@ -114,7 +114,8 @@ class Trainer:
         first = next(iter(self.saes.values()))
         self.initial_k = min(first.num_latents, round(first.d_in * 10))       # trainer.py:176-177
         self.final_k = cfg.sae.k
-        self.best_loss = {name: float("inf") for name in self.local_hookpoints()}
+        self.best_loss = ({name: float("inf") for name in self.saes} if cfg.loss_fn == "fvu"
+                          else float("inf"))                                # trainer.py:180-184
         self.num_tokens_in_step = 0
         self._metrics = defaultdict(lambda: torch.zeros((), device=self.device))
         self._pending: list = []
@@ -309,10 +310,12 @@ class Trainer:
                 ops.dead_counter_step_(counts, self.did_fire[name], self.num_tokens_in_step)
             self.num_tokens_in_step = 0
             did_step = True
-            if (step + 1) % cfg.save_every == 0:
-                self.save()
             if (step + 1) % cfg.wandb_log_frequency == 0:
                 self._flush_metrics(step)
+            if (step + 1) % cfg.save_every == 0:
+                self.save()
+                if cfg.save_best:                                           # trainer.py:543-544
+                    self.save_best(self._avg_losses())
         self.global_step += 1
         return did_step
 
@@ -331,6 +334,13 @@ class Trainer:
         info["step"] = step
         self.last_logged = info
         self._metrics.clear()
+
+    def _avg_losses(self) -> float | dict[str, float]:
+        """Losses of the last logged window: per-coder FVU, or the one ce / kl scalar (the
+        reference's `avg_losses`, trainer.py:501-506); a missing value never beats the best."""
+        if self.cfg.loss_fn != "fvu":
+            return self.last_logged.get(f"{self.cfg.loss_fn}_loss", float("inf"))
+        return {name: self.last_logged.get(f"fvu/{name}", float("inf")) for name in self.saes}
 
     def train_micro_batch(self, batch: dict, mask: Tensor | None = None):
         """One iteration of the reference's outer loop (trainer.py:453-589) for a batch of
@@ -366,6 +376,8 @@ class Trainer:
                 continue                       # resume: skip what was already consumed
             self.train_micro_batch(batch)
         self.save()
+        if self.cfg.save_best:                                              # trainer.py:592-594
+            self.save_best(self._avg_losses())
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:186-227, 648-724)
     def _checkpoint(self, saes: dict[str, SparseCoder], path: str, rank_zero: bool):
@@ -397,6 +409,27 @@ class Trainer:
         if dist.is_initialized():
             dist.barrier()
 
+    def save_best(self, avg_loss: float | dict[str, float]):
+        """trainer.py:701-724: keep, per coder (fvu) or for the whole set (ce / kl: one scalar),
+        the checkpoint with the lowest loss under {run}/best."""
+        base_path = f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}/best'
+        rank_zero = not dist.is_initialized() or dist.get_rank() == 0
+        writer = bool(self.cfg.save_dir) and (rank_zero or self.cfg.distribute_modules)
+        if isinstance(avg_loss, dict):
+            for name in self.saes:
+                if avg_loss[name] < self.best_loss[name]:
+                    self.best_loss[name] = avg_loss[name]
+                    if writer:
+                        Path(f"{base_path}/{name}").mkdir(parents=True, exist_ok=True)
+                        self._checkpoint({name: self.saes[name]}, f"{base_path}/{name}", rank_zero)
+        elif avg_loss < self.best_loss:
+            self.best_loss = avg_loss
+            if writer:
+                Path(base_path).mkdir(parents=True, exist_ok=True)
+                self._checkpoint(self.saes, base_path, rank_zero)
+        if dist.is_initialized():
+            dist.barrier()
+
     def load_state(self, path: str):
         from glob import glob
 
@@ -410,7 +443,9 @@ class Trainer:
             for k in self.saes:
                 if k in rank_state["num_tokens_since_fired"]:
                     self.num_tokens_since_fired[k] = rank_state["num_tokens_since_fired"][k]
-                if isinstance(rank_state["best_loss"], dict) and k in rank_state["best_loss"]:
+                if not isinstance(rank_state["best_loss"], dict):
+                    self.best_loss = rank_state["best_loss"]
+                elif k in rank_state["best_loss"]:
                     self.best_loss[k] = rank_state["best_loss"][k]
         for i, scheduler in enumerate(self.lr_schedulers):
             scheduler.load_state_dict(torch.load(f"{path}/lr_scheduler_{i}.pt", map_location=device, weights_only=True))

@@ -101,6 +101,39 @@ def test_trainer_optimizers_reduce_fvu(device, optimizer, tmp_path):
     assert "auxk/h0" in tr.last_logged and "dead_pct/h0" in tr.last_logged
 
 
+def test_trainer_save_best(device, tmp_path):
+    """trainer.py:540-544, 701-724: at every save_every-th step the per-coder best FVU is
+    tracked and the coder written under {run}/best/{name}; a worse loss overwrites nothing."""
+    from sparsify_amd import SparseCoder, SparseCoderConfig, TrainConfig
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N, steps = 32, 256, 4, 256, 6
+    batches = [b.cuda() for b in make_batches(steps, N, D)]
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", save_dir=str(tmp_path),
+                      run_name="run", save_every=2, save_best=True)
+    tr = Trainer(cfg, ListSource(batches, D), device="cuda")
+    best = tmp_path / "run" / "best" / "h0"
+    seen = []
+    for b in batches:
+        tr.train_micro_batch({"h0": b})
+        seen.append(tr.last_logged["fvu/h0"])
+    # step = (global_step + 1) // grad_acc_steps and saves happen when (step + 1) % save_every == 0
+    # (trainer.py:511, 540): with save_every = 2 that is the 1st, 3rd and 5th batch
+    saved_at = [seen[i] for i in (0, 2, 4)]
+    assert tr.best_loss["h0"] == min(saved_at)
+    assert (best / "h0" / "sae.safetensors").exists() and (best / "state.pt").exists()
+    kept = SparseCoder.load_from_disk(best / "h0", device="cuda")
+    if saved_at[-1] == min(saved_at):                            # the last save was the best one
+        assert torch.equal(kept.W_dec, tr.saes["h0"].W_dec)
+    tr.best_loss["h0"] = -1.0                                    # nothing beats this
+    stamp = (best / "h0" / "sae.safetensors").stat().st_mtime_ns
+    tr.save_best({"h0": 0.5})
+    assert (best / "h0" / "sae.safetensors").stat().st_mtime_ns == stamp and tr.best_loss["h0"] == -1.0
+    tr2 = Trainer(cfg, ListSource(batches, D), device="cuda")
+    tr2.load_state(str(tmp_path / "run"))
+    # the last periodic save ran inside the 5th batch, before global_step was advanced
+    assert tr2.best_loss["h0"] == min(saved_at) and tr2.global_step == 4
+
+
 def test_trainer_grad_accumulation_and_k_decay(device):
     from sparsify_amd import SparseCoderConfig, TrainConfig
     from sparsify_amd.trainer import Trainer

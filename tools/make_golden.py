@@ -329,10 +329,54 @@ def gen_trajectory():
          fvu_bf16=curves["bf16"])
 
 
+# ------------------------------------------------------------------ 7. checkpoints
+def gen_checkpoint():
+    """Checkpoints written by the reference's own save_to_disk (sparse_coder.py:167-179):
+    the files a user of the reference holds. tests/ load them through the build's
+    load_from_disk. The reverse direction (the build writes, the reference loads) can only be
+    checked here, where the reference is importable; it is asserted below."""
+    import json
+    import tempfile
+    D, M, k, N = 48, 384, 10, 64
+    for tag, kw in (("sae", dict(transcode=False, skip=False)),
+                    ("transcoder_skip", dict(transcode=True, skip=True))):
+        sae = make_sae(D, M, k, multi_topk=False, seed=3, **kw)
+        path = OUT / f"ckpt_{tag}"
+        sae.save_to_disk(path)
+        torch.manual_seed(321)
+        x = torch.randn(N, D) + torch.randn(D)
+        y = x @ (torch.randn(D, D) / D**0.5) if kw["transcode"] else None
+        back = SparseCoder.load_from_disk(path)
+        out = back(x, y)
+        acts, idx = sort_by_index(out.latent_acts, out.latent_indices)
+        arrays = dict(x=x, sae_out=out.sae_out, latent_acts=acts, latent_indices=idx, fvu=out.fvu)
+        if y is not None:
+            arrays["y"] = y
+        save(f"ckpt_{tag}_io", **arrays)
+        for f in sorted(path.iterdir()):
+            print(f"  {path.name}/{f.name}  {f.stat().st_size/1024:.0f} KiB")
+
+        # reverse: a checkpoint written by the build must load in the reference, bit for bit
+        sys.path.insert(0, str(OUT.parent.parent))
+        from sparsify_amd import SparseCoder as Ours
+        ours = Ours.load_from_disk(path)
+        with tempfile.TemporaryDirectory() as tmp:
+            ours.save_to_disk(tmp)
+            theirs = SparseCoder.load_from_disk(tmp)
+            with open(f"{tmp}/cfg.json") as fa, open(path / "cfg.json") as fb:
+                ca, cb = json.load(fa), json.load(fb)
+            assert ca == cb, (ca, cb)
+        ref_sd, got_sd = sae.state_dict(), theirs.state_dict()
+        assert ref_sd.keys() == got_sd.keys()
+        for key in ref_sd:
+            assert torch.equal(ref_sd[key], got_sd[key]), key
+        print(f"  reverse interop ({tag}): build-written checkpoint loads in the reference, equal")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encoder", "decode", "coder", "dense", "muon", "trajectory"]
+    which = sys.argv[1:] or ["encoder", "decode", "coder", "dense", "muon", "trajectory", "checkpoint"]
     table = dict(encoder=gen_encoder, decode=gen_decode, coder=gen_sparse_coder, dense=gen_dense,
-                 muon=gen_muon, trajectory=gen_trajectory)
+                 muon=gen_muon, trajectory=gen_trajectory, checkpoint=gen_checkpoint)
     for w in which:
         print(f"[{w}]")
         table[w]()
