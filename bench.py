@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 activations / no autocast (not the headline)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearsal with --gpus 1: run the data-parallel gradient exchange over a one-rank group")
+    ap.add_argument("--no-overlap", action="store_true", help="gradient exchange on the compute stream (A/B)")
     args = ap.parse_args()
 
     if os.environ.get("SPHIP_HANG_DUMP"):      # debugging aid: dump all stacks if the run stalls
@@ -122,6 +125,11 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
+    elif args.force_exchange:
+        dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                **({"device_id": device} if args.backend == "nccl" else {}))
+        from sparsify_amd import parallel as _par
+        _par.SignExchange.FORCE = True
 
     from sparsify_amd import SparseCoderConfig, TrainConfig, ops
     from sparsify_amd.trainer import SyntheticActivations, Trainer
@@ -129,7 +137,8 @@ def main():
     w = WORKLOADS[args.workload]
     N, D, M, k = args.tokens, w["d_in"], w["num_latents"], w["k"]
     cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["layers.10"],
-                      save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False)
+                      save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False,
+                      overlap_exchange=not args.no_overlap)
     total = args.warmup + args.steps
     src = SyntheticActivations(["layers.10"], D, N, total, device=device,
                                dtype=torch.float32 if args.fp32 else torch.bfloat16, rank=rank)
@@ -168,8 +177,12 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        gemm = kern["sphip_encoder_preacts"]
-        flops = 2.0 * N * D * M                                   # algorithmic FLOP per launch
+        # one launch per step, or one per latent block when the forward follows an overlapped
+        # gradient exchange (N > 1): the roofline figure is per step either way
+        gemm_ms = sum(kern[n]["total_ms"] for n in ("sphip_encoder_preacts", "sphip_encoder_preacts_block")
+                      if n in kern) / args.steps
+        gemm = {"mean_ms": gemm_ms}
+        flops = 2.0 * N * D * M                                   # algorithmic FLOP per step
         tflops = flops / (gemm["mean_ms"] * 1e-3) / 1e12
         dec = kern["sphip_gather_rows_weighted"]
         wg = kern["sphip_segmented_weight_grad"]
@@ -209,7 +222,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_tokens)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

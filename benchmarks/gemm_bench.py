@@ -1,6 +1,8 @@
 """Times sphip_encoder_preacts alone at the headline shape (bf16, N=16384, D=4096, M=131072).
 Usage: python benchmarks/gemm_bench.py [diag ...]   (diag = SPHIP_GEMM_DIAG values to sweep; non-zero
-values need a library built with `make -C sparsify_amd/csrc clean all DIAG=1`)"""
+values need a library built with `make -C sparsify_amd/csrc clean all DIAG=1`; "lib" = the vendor
+library's GEMM alone through torch, F.linear without bias or ReLU, "libref" = what the reference
+launches, relu(F.linear(x, W, b)), both for comparison only)"""
 import os
 import sys
 
@@ -17,15 +19,26 @@ W = (torch.randn(M, D, device=dev, generator=g) / 64).to(torch.bfloat16)
 b = torch.zeros(M, device=dev, dtype=torch.bfloat16)
 diags = sys.argv[1:] or ["0"]
 res = {dg: [] for dg in diags}
+
+
+def launch(dg):
+    if dg == "lib":
+        return torch.nn.functional.linear(x, W)
+    if dg == "libref":
+        return torch.relu(torch.nn.functional.linear(x, W, b))
+    return ops.encoder_preacts(x, W, b)
+
+
 for rnd in range(3):                      # interleaved rounds: variants share the device's state
     for dg in diags:
-        os.environ["SPHIP_GEMM_DIAG"] = dg
-        ops.encoder_preacts(x, W, b)
+        if not dg.startswith("lib"):
+            os.environ["SPHIP_GEMM_DIAG"] = dg
+        launch(dg)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.encoder_preacts(x, W, b)
+            launch(dg)
         e1.record()
         torch.cuda.synchronize()
         res[dg].append(e0.elapsed_time(e1) / 5)

@@ -65,6 +65,18 @@ int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* 
                           void* tile_max, int dtype, int64_t N, int64_t D, int64_t M, int relu,
                           void* stream);
 
+/* The same product (fused_encoder.py:29) for one block of M_block consecutive latents of a
+ * wider encoder: W, bias, pre and tile_max point at the block's first latent (row of W,
+ * element of bias, column of pre, block of tile_max); ld_pre is the row stride of pre and
+ * tiles_total the row length T of tile_max, i.e. those of the whole (N, M) matrix. Calls over
+ * disjoint blocks fill the same pre / tile_max as one sphip_encoder_preacts call, so a
+ * data-parallel trainer can start the forward on the latents whose averaged update
+ * (trainer.py:457-468) has arrived while the rest is still on the wire. bf16 only,
+ * M_block % SPHIP_TOPK_TILE == 0, ld_pre % 8 == 0, D % 64 == 0. */
+int sphip_encoder_preacts_block(const void* x, const void* W, const void* bias, void* pre,
+                                void* tile_max, int dtype, int64_t N, int64_t D, int64_t M_block,
+                                int64_t ld_pre, int64_t tiles_total, int relu, void* stream);
+
 /* torch.topk(pre, k, dim=-1, sorted=False), fused_encoder.py:33 -- and, with keep_mask,
  * torch.where(dead_mask[None], pre, -inf).topk(k_aux), sparse_coder.py:240-243.
  * pre (N,M) of `dtype`; keep_mask (M) uint8 or NULL; vals (N,k) of `dtype`; idx (N,k) int64.

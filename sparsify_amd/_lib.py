@@ -30,6 +30,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_center_cast": (_I, [_P, _I, _P, _P, _P, _L, _L, _P]),
     "sphip_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "sphip_encoder_preacts": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P]),
+    "sphip_encoder_preacts_block": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _P]),
     "sphip_topk": (_I, [_P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_groupmax": (_I, [_P, _I, _L, _L, _L, _P, _P, _P]),
     "sphip_gather_rows_weighted": (_I, [_P, _P, _I, _P, _P, _P, _L, _L, _L, _L, _P]),

@@ -70,6 +70,10 @@ class TrainConfig(_Serializable):
     exchange_signs: bool = True
     """(not in the reference) "signsgd" optimizer under DDP: exchange the large gradients as
     reduce-scatter + all-gather of 1-byte signs instead of an fp32 all-reduce (same update)."""
+    overlap_exchange: bool = True
+    """(not in the reference) run that exchange and the updates it feeds on a second stream, under
+    the next forward: the encoder GEMM follows the arriving row blocks (same update, same
+    results; parallel.wait_for_updates() before reading parameters outside the Trainer)."""
     save_every: int = 1000
     save_best: bool = False
     finetune: str | None = None

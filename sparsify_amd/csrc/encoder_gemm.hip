@@ -204,7 +204,8 @@ static int launch_gemm(const void* x, const void* W, const void* bias, void* pre
 }
 
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
-                         int64_t D, int64_t M, int relu, hipStream_t s, int* status);   // encoder_gemm256.hip
+                         int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s,
+                         int* status);   // encoder_gemm256.hip
 
 // Block maxima of pre for the kernels that do not take them in their epilogue (small shapes,
 // fp32): one wave per (token, 128-latent block). NaNs rank above +inf, as in topk.hip.
@@ -258,7 +259,7 @@ extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* b
         const char* force = getenv("SPHIP_GEMM");
         const bool want256 = force ? (force[0] == '2') : (cdiv(M, 256) * cdiv(N, 256) >= 256);
         int status = SPHIP_OK;
-        if (want256 && launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M, relu, s, &status)) return status;
+        if (want256 && launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M, M, cdiv(M, 128), relu, s, &status)) return status;
         status = launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);
         if (status != SPHIP_OK || tile_max == nullptr) return status;
         return launch_tile_max<bf16_t>(pre, tile_max, N, M, s);
@@ -266,4 +267,28 @@ extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* b
     const int status = launch_gemm<float>(x, W, bias, pre, N, D, M, relu, s);
     if (status != SPHIP_OK || tile_max == nullptr) return status;
     return launch_tile_max<float>(pre, tile_max, N, M, s);
+}
+
+extern "C" int sphip_encoder_preacts_block(const void* x, const void* W, const void* bias, void* pre, void* tile_max,
+                                           int dtype, int64_t N, int64_t D, int64_t M_block, int64_t ld_pre,
+                                           int64_t tiles_total, int relu, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(dtype == SPHIP_BF16, SPHIP_EUNSUPPORTED, "encoder_preacts_block: bf16 only");
+    SPHIP_REQUIRE(x && W && pre, SPHIP_EINVAL, "encoder_preacts_block: null pointer");
+    SPHIP_REQUIRE(N > 0 && D > 0 && M_block > 0, SPHIP_EINVAL, "encoder_preacts_block: empty shape");
+    SPHIP_REQUIRE(N < (1ll << 31) && ld_pre < (1ll << 31) && D < (1ll << 31), SPHIP_EUNSUPPORTED,
+                  "encoder_preacts_block: dimension exceeds int32");
+    SPHIP_REQUIRE(M_block % 128 == 0 && ld_pre >= M_block && ld_pre % 8 == 0, SPHIP_EINVAL,
+                  "encoder_preacts_block: the block must be whole 128-latent tiles of a row of ld_pre >= M_block, "
+                  "ld_pre a multiple of 8 (M_block=%lld ld_pre=%lld)", (long long)M_block, (long long)ld_pre);
+    SPHIP_REQUIRE(tile_max == nullptr || tiles_total >= M_block / 128, SPHIP_EINVAL,
+                  "encoder_preacts_block: tiles_total=%lld is shorter than the block", (long long)tiles_total);
+    SPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)pre & 15) == 0, SPHIP_EINVAL,
+                  "encoder_preacts_block: operands must be 16-byte aligned");
+    int status = SPHIP_OK;
+    if (launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M_block, ld_pre, tiles_total, relu, (hipStream_t)stream,
+                            &status))
+        return status;
+    set_error("encoder_preacts_block: D=%lld is not a multiple of 64", (long long)D);
+    return SPHIP_EUNSUPPORTED;
 }

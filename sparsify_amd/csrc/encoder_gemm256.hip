@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ bias,
                                                                  bf16_t* __restrict__ P, int N, int D, int M,
                                                                  int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
-                                                                 unsigned* dbg = nullptr) {
+                                                                 int64_t ldp, int tilesT, unsigned* dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
@@ -336,8 +336,9 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
     if (DIAG & 8) return;
     const int chunk = lane & 15;
     const int mcol = m0 + wm * 128 + chunk * 8;
-    const bool vec = (M & 7) == 0;
-    const int tilesT = (M + 127) >> 7;                  // row length of tile_max
+    // ldp: row stride of P; tilesT: row length of tile_max (both those of the whole matrix when
+    // this launch computes a block of latents, sphip_encoder_preacts_block)
+    const bool vec = (M & 7) == 0 && (ldp & 7) == 0;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int tok = i * 4 + (lane >> 4);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                 tile_max[((int64_t)(n >> 6) * tilesT + ((m0 + wm * 128) >> 7)) * 64 + (n & 63)] = KeyOf<bf16_t>::value(kmax);
         }
         if (n >= N || mcol >= M) continue;
-        bf16_t* dst = P + (int64_t)n * M + mcol;
+        bf16_t* dst = P + (int64_t)n * ldp + mcol;
         if (vec) {
             *reinterpret_cast<uint4*>(dst) = v;
         } else {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
-                         int64_t D, int64_t M, int relu, hipStream_t s, int* status) {
+                         int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s, int* status) {
     if (D % G_BK != 0 || D < G_BK) return false;
     const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
     const int64_t nblocks = (int64_t)tilesM * tilesN;
@@ -417,7 +418,7 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         (void)hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             G_LDS_BYTES);                                                                         \
         hipLaunchKernelGGL((encoder_gemm256_kernel<true, DG>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,       \
-                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, dbgp); \
+                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, dbgp); \
     }
     if (diag == 1) SPHIP_DIAG_LAUNCH(1)
     else if (diag == 2) SPHIP_DIAG_LAUNCH(2)
@@ -445,10 +446,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
 #endif
     if (relu)
         hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT);
     else
         hipLaunchKernelGGL((encoder_gemm256_kernel<false>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("encoder_preacts(256): launch failed: %s", hipGetErrorString(e));

@@ -15,7 +15,7 @@ from typing import Literal, NamedTuple
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops, parallel
 
 
 class EncoderOutput(NamedTuple):
@@ -60,6 +60,11 @@ def peek_bf16_shadow(t: Tensor) -> Tensor | None:
     return hit[1] if hit is not None and hit[1].shape == t.shape else None
 
 
+def shadow_is_current(t: Tensor) -> bool:
+    hit = _shadows.get(t.data_ptr())
+    return hit is not None and hit[0] == (t._version, tuple(t.shape))
+
+
 def _autocast_bf16() -> bool:
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
@@ -93,7 +98,23 @@ class FusedEncoder(torch.autograd.Function):
             if low:
                 x_low = x2 if x2.dtype == torch.bfloat16 else ops.center_cast(x2, None, False, True)[1]
         tile_max = None
-        if low:
+        # an overlapped data-parallel update of the weight (sign_sgd.SignSGD(overlap=True)) may
+        # still be arriving, row block by row block: the GEMM then follows it block by block
+        blocks = parallel.pending_blocks(weight)
+        if blocks and not (low and len(blocks) > 1 and shadow_is_current(weight) and x_low.shape[1] % 64 == 0):
+            torch.cuda.current_stream(weight.device).wait_event(blocks[-1][2])
+            blocks = None
+        if low and blocks:
+            N, M = x_low.shape[0], weight.shape[0]
+            pre = torch.empty(N, M, dtype=torch.bfloat16, device=x_low.device)
+            if activation == "topk":
+                tile_max = torch.empty(-(-N // 64), -(-M // ops.TOPK_TILE), 64, dtype=torch.bfloat16, device=x_low.device)
+            w_low, b_low = bf16_shadow(weight), None if bias is None else bf16_shadow(bias)
+            cur = torch.cuda.current_stream(weight.device)
+            for lo, hi, ev in blocks:
+                cur.wait_event(ev)
+                ops.encoder_preacts_block(x_low, w_low, b_low, pre, tile_max, lo, hi)
+        elif low:
             # the bf16 GEMM epilogue also leaves the maximum of every 128-latent block of pre;
             # top-k then reads only the ~k blocks per row that can hold a selected latent
             pre = ops.encoder_preacts(x_low, bf16_shadow(weight), None if bias is None else bf16_shadow(bias),

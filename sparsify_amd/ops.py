@@ -137,6 +137,33 @@ def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True
     return (pre, tmax) if want_tile_max else pre
 
 
+def encoder_preacts_block(x: Tensor, W: Tensor, bias: Tensor | None, pre: Tensor, tile_max: Tensor | None,
+                          lo: int, hi: int, relu: bool = True) -> None:
+    """Fills pre[:, lo:hi] (and the matching blocks of tile_max) from rows lo:hi of W: one latent
+    block of encoder_preacts, written into the caller's full-width buffers."""
+    _req(x, "x", torch.bfloat16, 2)
+    _req(W, "weight", torch.bfloat16, 2)
+    _req(pre, "pre_acts", torch.bfloat16, 2)
+    N, D = x.shape
+    M = W.shape[0]
+    if W.shape[1] != D or pre.shape != (N, M) or (bias is not None and bias.shape != (M,)):
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(W.shape)}, pre {tuple(pre.shape)}")
+    if not (0 <= lo < hi <= M) or lo % TOPK_TILE or (hi - lo) % TOPK_TILE:
+        raise ValueError(f"latent block [{lo}, {hi}) must be whole {TOPK_TILE}-latent tiles inside [0, {M})")
+    T = -(-M // TOPK_TILE)
+    if tile_max is not None:
+        _req(tile_max, "tile_max", torch.bfloat16, 3)
+        if tuple(tile_max.shape) != (-(-N // 64), T, 64):
+            raise ValueError(f"tile_max must be ({-(-N // 64)}, {T}, 64), got {tuple(tile_max.shape)}")
+    es = 2
+    _ev = timer.start("sphip_encoder_preacts_block", x)
+    check(_lib.load().sphip_encoder_preacts_block(
+        x.data_ptr(), W.data_ptr() + lo * D * es, None if bias is None else _req(bias, "bias", torch.bfloat16, 1).data_ptr() + lo * es,
+        pre.data_ptr() + lo * es, None if tile_max is None else tile_max.data_ptr() + (lo // TOPK_TILE) * 64 * es,
+        BF16, N, D, hi - lo, M, T, int(relu), _stream(x)), "sphip_encoder_preacts_block")
+    timer.stop(_ev, x)
+
+
 def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None, tile_max: Tensor | None = None):
     """torch.topk(pre, k, sorted=False) (optionally restricted to keep_mask); fused_encoder.py:33.
     tile_max: the block maxima encoder_preacts(..., want_tile_max=True) returned for this `pre`."""

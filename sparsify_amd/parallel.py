@@ -110,6 +110,52 @@ class GradReducer:
                 p.grad /= w
 
 
+# ------------------------------------------------------------------ overlapped updates
+# A parameter update that is still running on the exchange stream is recorded here as
+# (row_lo, row_hi, event) per finished row block; every reader of the parameter in this package
+# (FusedEncoder.forward, the decode op, the SparseCoder row operations, checkpointing) first makes
+# its own stream wait for those events. Code outside the package that reads parameters directly
+# right after Optimizer.step() must call wait_for_updates() first; the overlap is therefore
+# opt-in (SignSGD(overlap=True), TrainConfig.overlap_exchange for the Trainer).
+_side_streams: dict[int, "torch.cuda.Stream"] = {}
+_pending: dict[int, list] = {}
+
+
+def exchange_stream(device: torch.device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def set_pending(t: Tensor, blocks: list) -> None:
+    _pending[t.data_ptr()] = blocks
+
+
+def pending_blocks(t: Tensor) -> list | None:
+    """[(row_lo, row_hi, event)] of an update of `t` that may still be running, else None.
+    The caller takes over: it must wait for every event before reading those rows."""
+    return _pending.pop(t.data_ptr(), None)
+
+
+def wait_for(t: Tensor) -> None:
+    """Make the current stream wait until `t` holds its last update."""
+    blocks = _pending.pop(t.data_ptr(), None)
+    if blocks:
+        cur = torch.cuda.current_stream(t.device)
+        cur.wait_event(blocks[-1][2])              # blocks finish in order on one stream
+
+
+def wait_for_updates() -> None:
+    """Make the current stream of every device wait for all overlapped updates."""
+    for blocks in _pending.values():
+        if blocks:
+            ev = blocks[-1][2]
+            torch.cuda.current_stream().wait_event(ev)
+    _pending.clear()
+
+
 class SignExchange:
     """Gradient exchange of data-parallel SignSGD for the large matrices: the update only needs
     sign(mean gradient), so instead of all-reducing 4 B per element both ways
@@ -119,36 +165,62 @@ class SignExchange:
     (4 + 1) / (4 + 4) of the bytes over xGMI, and the result is exactly the update of the
     averaged gradient (trainer.py:457-468 + sign_sgd.py:23).
 
-    `sign_fn(grad_rows, row_lo, row_hi) -> int8 signs` and `apply_fn(signs_full)` are the
-    per-parameter kernels (sign_sgd.SignSGD passes the HIP ones)."""
+    `sign_fn(grad_rows, row_lo, row_hi) -> int8 signs` and `apply_fn(signs, row_lo, row_hi)` are
+    the per-parameter kernels (sign_sgd.SignSGD passes the HIP ones). With `blocks` > 1 the rows
+    are exchanged and updated block by block (block b = rows [b R/blocks, (b+1) R/blocks), of
+    which rank r reduces the r-th W-th), so that a reader can start on the first rows while the
+    later ones are still on the wire; every row gets the same update either way."""
 
     MIN_NUMEL = 1 << 20
+    FORCE = False          # tests / single-GPU rehearsals: exchange even with one rank
 
     @staticmethod
     def eligible(p: Tensor) -> bool:
         w = world_size()
-        return w > 1 and p.ndim == 2 and p.shape[0] % w == 0 and p.numel() >= SignExchange.MIN_NUMEL
+        if w == 1 and not (SignExchange.FORCE and dist.is_initialized()):
+            return False
+        return p.ndim == 2 and p.shape[0] % w == 0 and p.numel() >= SignExchange.MIN_NUMEL
 
     @staticmethod
-    def step(grad: Tensor, sign_fn, apply_fn) -> None:
+    def row_blocks(rows: int, want: int, multiple: int = 1) -> int:
+        """Largest block count <= want such that every block is a whole number of
+        `multiple`-row units per rank."""
+        w = world_size()
+        b = max(1, want)
+        while b > 1 and (rows % b or (rows // b) % (w * multiple)):
+            b -= 1
+        return b
+
+    @staticmethod
+    def step(grad: Tensor, sign_fn, apply_fn, blocks: int = 1, on_block=None) -> None:
         w, r = world_size(), rank()
-        rows = grad.shape[0] // w
+        total = grad.shape[0]
+        if total % (blocks * w):
+            raise ValueError(f"{total} rows do not split into {blocks} blocks of {w} equal shards")
+        per_block = total // blocks
+        rows = per_block // w
         grad = grad.contiguous()
-        shard = torch.empty(rows, *grad.shape[1:], dtype=grad.dtype, device=grad.device)
-        if dist.get_backend() == "nccl":
-            dist.reduce_scatter_tensor(shard, grad, op=dist.ReduceOp.AVG)
-        elif _host_staged(grad):
-            h = torch.empty(shard.shape, dtype=shard.dtype)
-            dist.reduce_scatter_tensor(h, grad.cpu(), op=dist.ReduceOp.SUM)
-            shard.copy_(h)
-            shard /= w
-        else:
-            dist.reduce_scatter_tensor(shard, grad, op=dist.ReduceOp.SUM)
-            shard /= w
-        signs = sign_fn(shard, r * rows, (r + 1) * rows)
-        full = torch.empty(grad.shape, dtype=torch.int8, device=grad.device)
-        _all_gather_raw(full, signs.contiguous())
-        apply_fn(full)
+        backend = dist.get_backend()
+        for b in range(blocks):
+            lo = b * per_block
+            gb = grad[lo:lo + per_block]
+            shard = torch.empty(rows, *grad.shape[1:], dtype=grad.dtype, device=grad.device)
+            if backend == "nccl":
+                dist.reduce_scatter_tensor(shard, gb, op=dist.ReduceOp.AVG)
+            elif _host_staged(grad):
+                h = torch.empty(shard.shape, dtype=shard.dtype)
+                dist.reduce_scatter_tensor(h, gb.cpu(), op=dist.ReduceOp.SUM)
+                shard.copy_(h)
+                shard /= w
+            else:
+                dist.reduce_scatter_tensor(shard, gb, op=dist.ReduceOp.SUM)
+                shard /= w
+            signs = sign_fn(shard, lo + r * rows, lo + (r + 1) * rows)
+            full = torch.empty(per_block, *grad.shape[1:], dtype=torch.int8, device=grad.device)
+            _all_gather_raw(full, signs.contiguous())
+            apply_fn(full, lo, lo + per_block)
+            if on_block is not None:
+                on_block(lo, lo + per_block)
 
 
 def broadcast_parameters(params, src: int = 0):

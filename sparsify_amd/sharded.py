@@ -146,7 +146,7 @@ class ShardedSparseCoder(nn.Module):
         y2 = y.reshape(-1, y.shape[-1]).contiguous()
         tv = ops.total_variance(y2)
         fvu, _ = ResidualLoss.apply(sae_out, y, tv)
-        zero = sae_out.new_tensor(0.0)
+        zero = sae_out.new_zeros(())               # a fill kernel: new_tensor(0.0) is a blocking host copy
         return ForwardOutput(sae_out, top_acts, top_indices, fvu, zero, zero)
 
     @torch.no_grad()

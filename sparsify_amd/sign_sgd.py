@@ -13,15 +13,24 @@ from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
 class SignSGD(Optimizer):
     """Steepest descent in the L-infty norm. From <https://arxiv.org/abs/1802.04434>"""
 
-    def __init__(self, params, lr: float = 1e-3, exchange_signs: bool = False):
+    # row blocks of an overlapped exchange of the encoder matrix: the next forward's GEMM runs
+    # block by block behind the arriving updates (sphip_encoder_preacts_block)
+    OVERLAP_BLOCKS = 8
+
+    def __init__(self, params, lr: float = 1e-3, exchange_signs: bool = False, overlap: bool = False):
         """exchange_signs (not in the reference): under torch.distributed the optimizer itself
         averages the gradients of the large matrices across ranks, as a reduce-scatter plus an
         all-gather of 1-byte signs (parallel.SignExchange); the caller then all-reduces only
-        the parameters for which `reduces(p)` is False."""
+        the parameters for which `reduces(p)` is False.
+        overlap: run those exchanges and the updates they feed on a second stream, encoder
+        matrices first, so that step() returns at once and the next forward overlaps the
+        traffic. Readers inside this package wait for the rows they need; anything else that
+        reads the parameters must call parallel.wait_for_updates() first."""
         if lr <= 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
         super().__init__(params, {"lr": lr})
         self.exchange_signs = exchange_signs
+        self.overlap = overlap and exchange_signs
         # ids of "renorm_rows" parameters whose rows were left unit-norm by the last step();
         # the trainer consumes an id instead of normalising that decoder again
         self.renormalised: set[int] = set()
@@ -32,6 +41,7 @@ class SignSGD(Optimizer):
     @torch.no_grad()
     def step(self, closure: None = None) -> None:
         assert closure is None, "Closure is not supported."
+        deferred = []
         for group in self.param_groups:
             lr = group["lr"]
             project = group.get("project_rows", False)
@@ -41,7 +51,10 @@ class SignSGD(Optimizer):
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if self.reduces(p):
-                    self._exchange_step(p, g, lr, project, renorm)
+                    if self.overlap and p.is_cuda:
+                        deferred.append((p, g, lr, project, renorm))
+                    else:
+                        self._exchange_step(p, g, lr, project, renorm)
                     continue
                 if project:
                     # decoder matrix: remove_gradient_parallel_to_decoder_directions
@@ -59,24 +72,47 @@ class SignSGD(Optimizer):
                 if shadow is not None:
                     register_bf16_shadow(p, shadow)
 
-    def _exchange_step(self, p, g, lr, project: bool, renorm: bool):
+        # overlapped exchanges, in the order the next forward needs the results: encoder
+        # matrices (read by the GEMM that opens it) before decoder matrices (read after top-k)
+        for item in sorted(deferred, key=lambda it: it[3]):
+            self._exchange_step(*item, overlap=True)
+
+    def _exchange_step(self, p, g, lr, project: bool, renorm: bool, overlap: bool = False):
         """One large matrix under data parallelism: see parallel.SignExchange."""
         w = p.data
         if project:
             def sign_fn(shard, lo, hi):
                 return ops.decoder_project_sign_i8(w[lo:hi], shard)
 
-            def apply_fn(signs):
-                ops.decoder_apply_signs_(w, signs, lr, renorm)
+            def apply_fn(signs, lo, hi):
+                ops.decoder_apply_signs_(w[lo:hi], signs, lr, renorm)
         else:
             shadow = peek_bf16_shadow(p)
 
             def sign_fn(shard, lo, hi):
                 return ops.sign_i8(shard)
 
-            def apply_fn(signs):
-                ops.apply_signs_(w, signs, lr, shadow)
-        parallel.SignExchange.step(g, sign_fn, apply_fn)
+            def apply_fn(signs, lo, hi):
+                ops.apply_signs_(w[lo:hi], signs, lr, None if shadow is None else shadow[lo:hi])
+        if overlap:
+            cur = torch.cuda.current_stream(p.device)
+            side = parallel.exchange_stream(p.device)
+            parallel.wait_for(p)                   # an earlier update of p that nobody read
+            side.wait_stream(cur)                  # the gradient (and p's last readers) are done
+            g.record_stream(side)                  # zero_grad() must not recycle it under the exchange
+            blocks = 1 if project else parallel.SignExchange.row_blocks(p.shape[0], self.OVERLAP_BLOCKS, 256)
+            done: list = []
+
+            def on_block(lo, hi):
+                ev = torch.cuda.Event()
+                ev.record(side)
+                done.append((lo, hi, ev))
+
+            with torch.cuda.stream(side):
+                parallel.SignExchange.step(g, sign_fn, apply_fn, blocks=blocks, on_block=on_block)
+            parallel.set_pending(p, done)
+        else:
+            parallel.SignExchange.step(g, sign_fn, apply_fn)
         torch.autograd.graph.increment_version(p)
         if project and renorm:
             self.renormalised.add(id(p))

@@ -12,7 +12,7 @@ from typing import NamedTuple
 import torch
 from torch import Tensor, nn
 
-from . import ops
+from . import ops, parallel
 from .config import SparseCoderConfig
 from .fused_encoder import EncoderOutput, FusedEncoder
 from .utils import SparseDecode, decoder_impl
@@ -148,6 +148,7 @@ class SparseCoder(nn.Module):
 
         path = Path(path)
         path.mkdir(parents=True, exist_ok=True)
+        parallel.wait_for_updates()               # overlapped optimizer updates (sign_sgd.py)
         save_model(self, str(path / "sae.safetensors"))
         with open(path / "cfg.json", "w") as f:
             json.dump({**self.cfg.to_dict(), "d_in": self.d_in}, f)
@@ -187,6 +188,7 @@ class SparseCoder(nn.Module):
 
         sae_out = self.decode(top_acts, top_indices)
         if self.W_skip is not None:
+            parallel.wait_for(self.W_skip)
             sae_out = sae_out + x.to(self.dtype) @ self.W_skip.mT
 
         y2 = y.reshape(-1, y.shape[-1]).contiguous()
@@ -205,7 +207,7 @@ class SparseCoder(nn.Module):
             auxk_sq, _ = ResidualLoss.apply(e_hat, e, total_variance)                  # :248-249
             auxk_loss = scale * auxk_sq
         else:
-            auxk_loss = sae_out.new_tensor(0.0)
+            auxk_loss = sae_out.new_zeros(())      # a fill kernel: new_tensor(0.0) is a blocking host copy
 
         if self.cfg.multi_topk:
             pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
@@ -215,7 +217,7 @@ class SparseCoder(nn.Module):
             sae_out = self.decode(top_acts, top_indices)
             multi_topk_fvu, _ = ResidualLoss.apply(sae_out, y, total_variance)         # :260
         else:
-            multi_topk_fvu = sae_out.new_tensor(0.0)
+            multi_topk_fvu = sae_out.new_zeros(())
 
         return ForwardOutput(sae_out, top_acts, top_indices, fvu, auxk_loss, multi_topk_fvu)
 
@@ -223,6 +225,7 @@ class SparseCoder(nn.Module):
     def set_decoder_norm_to_unit_norm(self):
         """sparse_coder.py:273-279, one fused pass over W_dec."""
         assert self.W_dec is not None, "Decoder weight was not initialized."
+        parallel.wait_for(self.W_dec)
         ops.unit_norm_rows_(self.W_dec.data)
         torch.autograd.graph.increment_version(self.W_dec)
 
@@ -231,6 +234,7 @@ class SparseCoder(nn.Module):
         """sparse_coder.py:281-295, one fused pass over (W_dec.grad, W_dec)."""
         assert self.W_dec is not None, "Decoder weight was not initialized."
         assert self.W_dec.grad is not None
+        parallel.wait_for(self.W_dec)
         ops.remove_parallel_grad_(self.W_dec.grad, self.W_dec.data)
 
 

@@ -168,7 +168,7 @@ class Trainer:
                     opt.train()
                     self.optimizers = [opt]
                 else:
-                    self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs)]
+                    self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange)]
                 self._fused_projection = project
             case other:
                 raise ValueError(f"Unknown optimizer '{other}'")
@@ -375,12 +375,14 @@ class Trainer:
             if i < self.global_step:
                 continue                       # resume: skip what was already consumed
             self.train_micro_batch(batch)
+        parallel.wait_for_updates()
         self.save()
         if self.cfg.save_best:                                              # trainer.py:592-594
             self.save_best(self._avg_losses())
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:186-227, 648-724)
     def _checkpoint(self, saes: dict[str, SparseCoder], path: str, rank_zero: bool):
+        parallel.wait_for_updates()
         for optimizer in self.optimizers:
             if isinstance(optimizer, ScheduleFreeWrapper):
                 optimizer.eval()

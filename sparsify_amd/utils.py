@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops, parallel
 
 
 class SparseDecode(torch.autograd.Function):
@@ -15,6 +15,7 @@ class SparseDecode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, indices: Tensor, weight: Tensor, per_sample_weights: Tensor, bias: Tensor | None = None):
         ops.forget_segments(indices)
+        parallel.wait_for(weight)                  # an overlapped optimizer update (sign_sgd.py)
         w = weight.detach()
         out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
                                        None if bias is None else bias.detach())

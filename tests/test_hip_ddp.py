@@ -1,8 +1,10 @@
 """Data-parallel Trainer with two ranks on ONE GPU (gloo rendezvous, device tensors staged
 through the host): the N > 1 code of bench.py / Trainer runs end to end with the HIP kernels,
-replicas stay identical, and the sign exchange (reduce-scatter + all-gather of int8 signs)
-gives bit for bit the parameters of the plain gradient all-reduce. The RCCL backend itself
-only runs on a multi-GPU node (the driver's scaling bench)."""
+replicas stay identical, and the sign exchange (reduce-scatter + all-gather of int8 signs),
+on the compute stream or overlapped with the next forward, gives bit for bit the parameters
+of the plain gradient all-reduce. RCCL itself ("nccl") runs here as a one-rank group, which
+exercises its stream semantics under the overlapped exchange; more ranks need a multi-GPU
+node (the driver's scaling bench)."""
 import os
 import socket
 
@@ -20,6 +22,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
+MODES = ("allreduce", "exchange", "overlap")
+
+
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -29,9 +34,11 @@ def _worker(rank, world, port, ret):
         from sparsify_amd.trainer import SyntheticActivations, Trainer
         D, M, k, N, steps = 256, 4096, 16, 512, 4
         out = {}
-        for exchange in (False, True):
+        for mode in MODES:
+            exchange, overlap = mode != "allreduce", mode == "overlap"
             cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"],
-                              save_dir="", save_every=10**9, wandb_log_frequency=1, exchange_signs=exchange)
+                              save_dir="", save_every=10**9, wandb_log_frequency=1, exchange_signs=exchange,
+                              overlap_exchange=overlap)
             src = SyntheticActivations(["h0"], D, N, steps, device="cuda", rank=rank)
             torch.manual_seed(0)
             tr = Trainer(cfg, src, device="cuda")
@@ -39,8 +46,8 @@ def _worker(rank, world, port, ret):
                 tr.train_micro_batch(src.batch(s))
             sae = tr.saes["h0"]
             torch.cuda.synchronize()
-            out[exchange] = {n: p.detach().cpu() for n, p in sae.named_parameters()}
-            out[exchange]["fvu"] = tr.last_logged["fvu/h0"]
+            out[mode] = {n: p.detach().cpu() for n, p in sae.named_parameters()}
+            out[mode]["fvu"] = tr.last_logged["fvu/h0"]
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -62,14 +69,71 @@ def test_two_rank_trainer_sign_exchange_equals_all_reduce(device):
             pytest.fail("a rank did not finish (collective mismatch?)")
         assert p.exitcode == 0
     r0, r1 = ret[0], ret[1]
-    for mode in (False, True):
+    for mode in MODES:
         for name in r0[mode]:
             if name == "fvu":
                 assert r0[mode]["fvu"] == pytest.approx(r1[mode]["fvu"], rel=1e-6)     # logged mean over ranks
             else:
-                assert torch.equal(r0[mode][name], r1[mode][name]), f"replicas diverged: {name} (exchange={mode})"
-    # two ranks: a + b is order independent, so both exchanges see the same mean gradient
-    for name in r0[False]:
-        if name != "fvu":
-            assert torch.equal(r0[False][name], r0[True][name]), f"sign exchange != all-reduce: {name}"
-    assert r0[True]["fvu"] < 1.0
+                assert torch.equal(r0[mode][name], r1[mode][name]), f"replicas diverged: {name} ({mode})"
+    # two ranks: a + b is order independent, so every exchange sees the same mean gradient
+    for mode in MODES[1:]:
+        for name in r0["allreduce"]:
+            if name != "fvu":
+                assert torch.equal(r0["allreduce"][name], r0[mode][name]), f"{mode} != all-reduce: {name}"
+    assert r0["overlap"]["fvu"] < 1.0
+
+
+def _rccl_one_rank(port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from sparsify_amd import SparseCoderConfig, TrainConfig, ops, parallel
+        from sparsify_amd.trainer import SyntheticActivations, Trainer
+        D, M, k, N, steps = 1024, 16384, 32, 4096, 6
+        out = {}
+        for mode in MODES:
+            parallel.SignExchange.FORCE = mode != "allreduce"       # one rank: no exchange unless forced
+            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"],
+                              save_dir="", save_every=10**9, wandb_log_frequency=1, exchange_signs=True,
+                              overlap_exchange=mode == "overlap")
+            src = SyntheticActivations(["h0"], D, N, steps, device="cuda")
+            torch.manual_seed(0)
+            tr = Trainer(cfg, src, device="cuda")
+            ops.timer.enabled = True
+            ops.timer.reset()
+            for s in range(steps):
+                tr.train_micro_batch(src.batch(s))
+            parallel.wait_for_updates()
+            torch.cuda.synchronize()
+            ops.timer.enabled = False
+            out[mode] = {n: p.detach().cpu() for n, p in tr.saes["h0"].named_parameters()}
+            out[mode]["fvu"] = tr.last_logged["fvu/h0"]
+            out[mode]["block_launches"] = len(ops.timer.events.get("sphip_encoder_preacts_block", []))
+        ret[0] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_over_rccl_one_rank(device):
+    """The overlapped exchange on RCCL's own streams (a one-rank group: its reduce-scatter and
+    all-gather are copies, the stream and event choreography is the real one): six steps give
+    bit for bit the parameters of the plain single-stream SignSGD step, and from the second
+    step on the encoder GEMM ran block by block behind the arriving updates."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    proc = ctx.Process(target=_rccl_one_rank, args=(_free_port(), ret))
+    proc.start()
+    proc.join(timeout=100)
+    if proc.is_alive():
+        proc.kill()
+        pytest.fail("the rank did not finish")
+    assert proc.exitcode == 0
+    out = ret[0]
+    for mode in MODES[1:]:
+        for name, ref in out["allreduce"].items():
+            if name not in ("fvu", "block_launches"):
+                assert torch.equal(ref, out[mode][name]), f"{mode}: {name} differs from the plain step"
+        assert out[mode]["fvu"] == out["allreduce"]["fvu"]
+    assert out["allreduce"]["block_launches"] == 0 and out["exchange"]["block_launches"] == 0
+    assert out["overlap"]["block_launches"] == 5 * 8           # steps 2..6, SignSGD.OVERLAP_BLOCKS each

@@ -80,6 +80,32 @@ def test_encoder_preacts_256_tile_kernel(device, monkeypatch, N, D, M, relu):
     assert torch.equal(goti.float(), (xi.float() @ Wi.float().T).bfloat16().float())
 
 
+@pytest.mark.parametrize("N,D,M,cuts", [(300, 128, 1024, (0, 256, 1024)), (512, 256, 2048, (0, 512, 1024, 1536, 2048)),
+                                          (257, 64, 640, (0, 128, 640))])
+@pytest.mark.parametrize("relu", [True, False])
+def test_encoder_preacts_by_latent_blocks(device, monkeypatch, N, D, M, cuts, relu):
+    """sphip_encoder_preacts_block over disjoint latent blocks fills the same pre and block maxima
+    as one sphip_encoder_preacts call, bit for bit (same kernel, same per-tile arithmetic)."""
+    from sparsify_amd import ops
+    torch.manual_seed(N + M)
+    xb = dev(torch.randn(N, D).bfloat16())
+    Wb = dev((torch.randn(M, D) / D**0.5).bfloat16())
+    bb = dev((torch.randn(M) * 0.1).bfloat16())
+    monkeypatch.setenv("SPHIP_GEMM", "256")
+    whole, whole_max = ops.encoder_preacts(xb, Wb, bb, relu=relu, want_tile_max=True)
+    pre = torch.full_like(whole, float("nan"))
+    tmax = torch.full_like(whole_max, float("nan"))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ops.encoder_preacts_block(xb, Wb, bb, pre, tmax, lo, hi, relu=relu)
+    assert torch.equal(pre.view(torch.int16), whole.view(torch.int16))
+    rows = torch.arange(N, device=pre.device)
+    got = tmax[rows // 64, :, rows % 64].view(torch.int16)          # rows past N are undefined
+    assert torch.equal(got, whole_max[rows // 64, :, rows % 64].view(torch.int16))
+    with pytest.raises(ValueError):
+        ops.encoder_preacts_block(xb, Wb, bb, pre, tmax, 64, 256)    # not on a 128-latent boundary
+    assert ops.encoder_preacts_block(xb, Wb, None, pre, None, 0, 128, relu=relu) is None
+
+
 # ------------------------------------------------------------------ top-k
 def check_topk(pre_cpu, k, vals, idx, keep=None):
     """Set semantics of torch.topk: selected values are the k largest, indices are valid,

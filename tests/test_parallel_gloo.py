@@ -132,8 +132,16 @@ def _sign_exchange(rank, world):
     # plain
     p = W.clone()
     P.SignExchange.step(grads[rank], lambda s, lo, hi: torch.sign(s).to(torch.int8),
-                        lambda signs: p.sub_(lr * signs.float()))
+                        lambda signs, lo, hi: p[lo:hi].sub_(lr * signs.float()))
     ok_plain = torch.equal(p, W - lr * torch.sign(mean))
+    # the same update exchanged in row blocks (what the overlapped optimizer step does)
+    p2 = W.clone()
+    order = []
+    P.SignExchange.step(grads[rank], lambda s, lo, hi: torch.sign(s).to(torch.int8),
+                        lambda signs, lo, hi: p2[lo:hi].sub_(lr * signs.float()), blocks=2,
+                        on_block=lambda lo, hi: order.append((lo, hi)))
+    ok_plain = ok_plain and torch.equal(p2, p) and order == [(0, M // 2), (M // 2, M)]
+    ok_plain = ok_plain and P.SignExchange.row_blocks(M, 8) == M // world and P.SignExchange.row_blocks(M, 8, 256) == 1
     # decoder: sign of the projected gradient, taken on this rank's row block only
     q = W.clone()
     seen = []
@@ -143,7 +151,7 @@ def _sign_exchange(rank, world):
         w = W[lo:hi]
         return torch.sign(shard - (shard * w).sum(1, keepdim=True) * w).to(torch.int8)
 
-    P.SignExchange.step(grads[rank], proj_sign, lambda signs: q.sub_(lr * signs.float()))
+    P.SignExchange.step(grads[rank], proj_sign, lambda signs, lo, hi: q[lo:hi].sub_(lr * signs.float()))
     ref = W - lr * torch.sign(mean - (mean * W).sum(1, keepdim=True) * W)
     frac_bad = float((q != ref).float().mean())      # summation order of the reduce may flip a ~0 sign
     return ok_plain, frac_bad, seen[0] == (rank * M // world, (rank + 1) * M // world)
