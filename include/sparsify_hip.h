@@ -240,6 +240,38 @@ int sphip_dead_counter_step(int64_t* counts, uint8_t* did_fire, int64_t M, int64
 int sphip_dead_mask(const int64_t* counts, int64_t M, int64_t threshold, uint8_t* mask,
                     int32_t* n_dead, void* stream);
 
+/* AuxK over few dead latents as dense products (sparse_coder.py:230-251: the decode of the
+ * k_aux = d_in/2 best dead latents per token, self.decode(auxk_acts, auxk_indices), and its
+ * W_dec gradient). When the dead latents are few, the (tokens x dead latents) matrix of
+ * selected activations is dense enough for the matrix cores:
+ *     e_hat = A W_dead + b_dec,   W_dec.grad[dead] = A^T dL/de_hat.
+ * A is exact in bf16 (the activations are bf16 under autocast); the fp32 factor is split into
+ * three bf16 terms whose sum is the fp32 value, and the partial products are added in fp32,
+ * so the result differs from the fp32 embedding_bag only in the order of the additions.
+ *   sphip_dead_compact:          mask (M) uint8 -> slot_of (M) int32 (slot of a dead latent, else
+ *                                -1) and dead_list (slot -> latent, up to list_capacity)
+ *   sphip_dead_scatter_acts:     idx (N,k) int64 / acts (N,k) bf16 -> A (N, ldA) and A^T (Kd, ldT)
+ *                                bf16, zero-filled first; entries on latents that are not dead
+ *                                (or < 0) are skipped
+ *   sphip_split_bf16_transposed: fp32 rows src[row_list ? row_list[r] : r] (r < R, C columns) ->
+ *                                three (C, ldr) bf16 matrices, element [c][r]; columns R..ldr-1 zero
+ *   sphip_gemm_bf16_f32acc:      out (N, ld_out) fp32 (+)= x (N,K) W (M,K)^T, bf16 operands, fp32
+ *                                accumulate; accumulate != 0 adds to what out holds. K % 64 == 0
+ *   sphip_scatter_rows:          dst (M, D) = 0; dst[row_list[r], :] = src[r, :] for r < R
+ *   sphip_broadcast_rows:        out[n, :] = bias (the `+ b_dec` the products are added to) */
+int sphip_dead_compact(const uint8_t* mask, int64_t M, int32_t* slot_of, int64_t* dead_list,
+                       int64_t list_capacity, void* stream);
+int sphip_dead_scatter_acts(const int64_t* idx, const void* acts_bf16, const int32_t* slot_of,
+                            int64_t N, int64_t k, int64_t M, int64_t Kd, int64_t ldA, int64_t ldT,
+                            void* A, void* At, void* stream);
+int sphip_split_bf16_transposed(const float* src, const int64_t* row_list, int64_t R, int64_t C,
+                                int64_t ldr, void* hi, void* mid, void* lo, void* stream);
+int sphip_gemm_bf16_f32acc(const void* x, const void* W, float* out, int64_t N, int64_t K,
+                           int64_t M, int64_t ld_out, int accumulate, void* stream);
+int sphip_scatter_rows(const float* src, const int64_t* row_list, int64_t R, int64_t D, int64_t M,
+                       float* dst, void* stream);
+int sphip_broadcast_rows(const float* bias, int64_t N, int64_t D, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,12 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_decoder_project_signsgd": (_I, [_P, _P, _L, _L, _F, _I, _P]),
     "sphip_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
     "sphip_decoder_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P]),
+    "sphip_dead_compact": (_I, [_P, _L, _P, _P, _L, _P]),
+    "sphip_dead_scatter_acts": (_I, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _P, _P]),
+    "sphip_split_bf16_transposed": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
+    "sphip_gemm_bf16_f32acc": (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _P]),
+    "sphip_scatter_rows": (_I, [_P, _P, _L, _L, _L, _P, _P]),
+    "sphip_broadcast_rows": (_I, [_P, _L, _L, _P, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),
     "sphip_apply_signs": (_I, [_P, _P, _L, _F, _P, _P]),

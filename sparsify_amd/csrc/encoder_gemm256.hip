@@ -60,7 +60,10 @@ __device__ __forceinline__ void seg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool RELU, int DIAG = 0>
+// OUTF: 0 = the encoder's epilogue (bias, ReLU, bf16, block maxima); 1 = store the fp32
+// accumulators as they are (P is float*); 2 = add them to the fp32 values already in P
+// (sphip_gemm_bf16_f32acc: products whose fp32 operand was split into bf16 terms).
+template <bool RELU, int DIAG = 0, int OUTF = 0>
 __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* __restrict__ X,
                                                                  const bf16_t* __restrict__ W,
                                                                  const bf16_t* __restrict__ bias,
@@ -291,6 +294,30 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         for (int i = 0; i < 10; ++i) o[i] = tacc[i];
     }
 
+    if (OUTF != 0) {
+        // fp32 output: the lane's 4 consecutive columns of one row per accumulator tile, 16-B
+        // pieces straight from the registers (these products write N x M / K-fold fewer bytes
+        // than they read, the store shape does not matter)
+        float* Pf = reinterpret_cast<float*>(P);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + r16;
+                if (n >= N || m >= M) continue;                    // M % 4 == 0 (host check)
+                float4* dst = reinterpret_cast<float4*>(Pf + (int64_t)n * ldp + m);
+                float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+                if (OUTF == 2) {
+                    const float4 o = *dst;
+                    v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                }
+                *dst = v;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: + bias, relu, one rounding to bf16. A lane owns 4 consecutive latents of
     // one token per accumulator tile (C/D map of 16x16: col = lane&15, row = 4*(lane>>4)+reg),
     // i.e. 8-B pieces; the wave's 64 x 128 sub-tile goes through a private LDS area (the
@@ -458,6 +485,31 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         *status = SPHIP_OK;
     }
     return true;
+}
+
+// out (+)= x W^T in fp32 from bf16 operands: x (N,K), W (M,K), out (N, ld_out) float.
+int launch_gemm256_f32out(const void* x, const void* W, float* out, int64_t N, int64_t K, int64_t M, int64_t ld_out,
+                          int accumulate, hipStream_t s) {
+    const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
+    static bool attr_set[2] = {false, false};
+    const void* fn = accumulate ? (const void*)encoder_gemm256_kernel<false, 0, 2>
+                                : (const void*)encoder_gemm256_kernel<false, 0, 1>;
+    if (!attr_set[accumulate ? 1 : 0]) {
+        SPHIP_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES) == hipSuccess,
+                      SPHIP_ELAUNCH, "gemm_bf16_f32acc: cannot reserve %d bytes of LDS", G_LDS_BYTES);
+        attr_set[accumulate ? 1 : 0] = true;
+    }
+    dim3 grid((unsigned)((int64_t)tilesM * tilesN)), block(512);
+    if (accumulate)
+        hipLaunchKernelGGL((encoder_gemm256_kernel<false, 0, 2>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
+                           (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
+                           (bf16_t*)nullptr, ld_out, 0);
+    else
+        hipLaunchKernelGGL((encoder_gemm256_kernel<false, 0, 1>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
+                           (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
+                           (bf16_t*)nullptr, ld_out, 0);
+    SPHIP_CHECK_LAUNCH("gemm_bf16_f32acc");
+    return SPHIP_OK;
 }
 
 }  // namespace sphip

@@ -1,0 +1,75 @@
+"""AuxK decode over few dead latents as dense matrix-core products (sparse_coder.py:230-251).
+
+``self.decode(auxk_acts, auxk_indices)`` sums k_aux = d_in / 2 decoder rows per token, all of
+them rows of dead latents. As a row gather that is 10x the bytes of the main decode. When the
+dead latents are few the (tokens x dead latents) matrix A of selected activations is dense
+enough (k_aux / n_dead) that ``A @ W_dec[dead] + b_dec`` and ``A.T @ grad`` on the matrix cores
+are an order of magnitude cheaper. Exactness: see csrc/dead_dense.hip (A exact in bf16, the
+fp32 factor split into three bf16 terms, fp32 accumulation: only the summation order differs
+from the reference's fp32 embedding_bag)."""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import Tensor
+
+from . import ops, parallel
+
+# dense when n_dead <= DENSE_RATIO * k_aux: the gather moves k_aux * D * 4 bytes per token at
+# ~10 TB/s, the three bf16 products cost 6 * n_dead * D FLOP per token at ~1.3 PFLOP/s (x2 with
+# the gradient on both sides), which crosses near n_dead = 80 k_aux; the preparation passes and
+# the (N, n_dead) temporaries scale with n_dead too, so the switch is set well below that.
+DENSE_RATIO = 24
+MIN_ENTRIES = 1 << 22
+
+
+def eligible(acts: Tensor, W_dec: Tensor, num_dead: int) -> bool:
+    force = os.environ.get("SPHIP_AUXK")
+    if force == "gather" or acts.dtype != torch.bfloat16 or W_dec.dtype != torch.float32 or W_dec.shape[1] % 4:
+        return False
+    if force == "dense":
+        return True
+    k_aux = acts.shape[-1]
+    return num_dead <= DENSE_RATIO * k_aux and acts.numel() >= MIN_ENTRIES
+
+
+class DeadLatentDecode(torch.autograd.Function):
+    """decode(auxk_acts, auxk_indices) for indices that all lie on dead latents; gradients for
+    W_dec and b_dec only (the gradient w.r.t. the activations would flow into pre_acts, which
+    the encoder backward drops, fused_encoder.py:53,87)."""
+
+    @staticmethod
+    def forward(ctx, indices: Tensor, acts: Tensor, W_dec: Tensor, b_dec: Tensor, dead_mask: Tensor, num_dead: int):
+        parallel.wait_for(W_dec)
+        N = indices.shape[0]
+        M, D = W_dec.shape
+        Kd = -(-num_dead // 64) * 64
+        slot_of, dead_list = ops.dead_compact(dead_mask, num_dead)
+        A, At = ops.dead_scatter_acts(indices, acts.contiguous(), slot_of, Kd)
+        w_parts = ops.split_bf16_transposed(W_dec.detach(), dead_list, num_dead, Kd)      # 3 x (D, Kd)
+        out = ops.broadcast_rows(b_dec.detach(), N)
+        for p in range(3):
+            ops.gemm_bf16_f32acc(A, w_parts[p], out, accumulate=True)
+        ctx.save_for_backward(At, dead_list)
+        ctx.dims = (N, M, D, num_dead)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None, None
+        At, dead_list = ctx.saved_tensors
+        N, M, D, num_dead = ctx.dims
+        g = g.reshape(N, D).contiguous().float()
+        gW = gb = None
+        if ctx.needs_input_grad[2]:
+            g_parts = ops.split_bf16_transposed(g, None, N, At.shape[1])                  # 3 x (D, ceil64(N))
+            G = torch.empty(At.shape[0], D, dtype=torch.float32, device=g.device)
+            for p in range(3):
+                ops.gemm_bf16_f32acc(At, g_parts[p], G, accumulate=p > 0)
+            gW = ops.scatter_rows(G, dead_list, num_dead, M)
+        if ctx.needs_input_grad[3]:
+            gb = ops.colsum(g, 1.0)
+        return None, None, gW, gb, None, None

@@ -478,6 +478,90 @@ def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = Fal
     return W
 
 
+# ------------------------------------------------------------------ AuxK as dense products
+def dead_compact(dead_mask: Tensor, num_dead: int):
+    """dead_mask (M,) bool/uint8 -> slot_of (M,) int32 (slot or -1), dead_list (num_dead,) int64."""
+    _req(dead_mask, "dead_mask", ndim=1)
+    mask = dead_mask.view(torch.uint8) if dead_mask.dtype == torch.bool else _req(dead_mask, "dead_mask", torch.uint8)
+    M = mask.shape[0]
+    slot_of = torch.empty(M, dtype=torch.int32, device=mask.device)
+    dead_list = torch.empty(num_dead, dtype=torch.int64, device=mask.device)
+    check(_lib.load().sphip_dead_compact(mask.data_ptr(), M, slot_of.data_ptr(), dead_list.data_ptr(), num_dead,
+                                        _stream(mask)), "sphip_dead_compact")
+    return slot_of, dead_list
+
+
+def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor, Kd: int):
+    """Selected activations as dense bf16 matrices A (N, Kd) and A^T (Kd, ceil64(N))."""
+    _req(idx, "indices", torch.int64, 2)
+    _req(acts, "acts", torch.bfloat16, 2)
+    _req(slot_of, "slot_of", torch.int32, 1)
+    if acts.shape != idx.shape:
+        raise ValueError("dead_scatter_acts: shape mismatch")
+    N, k = idx.shape
+    ldT = -(-N // 64) * 64
+    A = torch.empty(N, Kd, dtype=torch.bfloat16, device=idx.device)
+    At = torch.empty(Kd, ldT, dtype=torch.bfloat16, device=idx.device)
+    check(_lib.load().sphip_dead_scatter_acts(idx.data_ptr(), acts.data_ptr(), slot_of.data_ptr(), N, k, slot_of.shape[0],
+                                             Kd, Kd, ldT, A.data_ptr(), At.data_ptr(), _stream(idx)),
+          "sphip_dead_scatter_acts")
+    return A, At
+
+
+def split_bf16_transposed(src: Tensor, row_list: Tensor | None, R: int, ldr: int):
+    """Three bf16 (C, ldr) matrices whose sum is fp32 src[rows].T exactly (columns R.. are zero)."""
+    _req(src, "src", torch.float32, 2)
+    if row_list is not None:
+        _req(row_list, "row_list", torch.int64, 1)
+        if row_list.shape[0] < R:
+            raise ValueError("split_bf16_transposed: row_list shorter than R")
+    elif src.shape[0] < R:
+        raise ValueError("split_bf16_transposed: src has fewer than R rows")
+    C = src.shape[1]
+    parts = torch.empty(3, C, ldr, dtype=torch.bfloat16, device=src.device)
+    check(_lib.load().sphip_split_bf16_transposed(src.data_ptr(), _ptr(row_list), R, C, ldr, parts[0].data_ptr(),
+                                                 parts[1].data_ptr(), parts[2].data_ptr(), _stream(src)),
+          "sphip_split_bf16_transposed")
+    return parts
+
+
+def gemm_bf16_f32acc(x: Tensor, W: Tensor, out: Tensor, accumulate: bool) -> Tensor:
+    """out (N, M) fp32 (+)= x (N, K) @ W (M, K).T with bf16 operands and fp32 accumulation."""
+    _req(x, "x", torch.bfloat16, 2)
+    _req(W, "W", torch.bfloat16, 2)
+    _req(out, "out", torch.float32, 2)
+    N, K = x.shape
+    M = W.shape[0]
+    if W.shape[1] != K or out.shape != (N, M):
+        raise ValueError(f"gemm_bf16_f32acc: x {tuple(x.shape)}, W {tuple(W.shape)}, out {tuple(out.shape)}")
+    _ev = timer.start("sphip_gemm_bf16_f32acc", x)
+    check(_lib.load().sphip_gemm_bf16_f32acc(x.data_ptr(), W.data_ptr(), out.data_ptr(), N, K, M, M, int(accumulate),
+                                            _stream(x)), "sphip_gemm_bf16_f32acc")
+    timer.stop(_ev, x)
+    return out
+
+
+def scatter_rows(src: Tensor, row_list: Tensor, R: int, M: int) -> Tensor:
+    """(M, D) zeros with row row_list[r] = src[r] for r < R."""
+    _req(src, "src", torch.float32, 2)
+    _req(row_list, "row_list", torch.int64, 1)
+    if src.shape[0] < R or row_list.shape[0] < R:
+        raise ValueError("scatter_rows: fewer than R rows")
+    D = src.shape[1]
+    dst = torch.empty(M, D, dtype=torch.float32, device=src.device)
+    check(_lib.load().sphip_scatter_rows(src.data_ptr(), row_list.data_ptr(), R, D, M, dst.data_ptr(), _stream(src)),
+          "sphip_scatter_rows")
+    return dst
+
+
+def broadcast_rows(bias: Tensor, N: int) -> Tensor:
+    _req(bias, "bias", torch.float32, 1)
+    out = torch.empty(N, bias.shape[0], dtype=torch.float32, device=bias.device)
+    check(_lib.load().sphip_broadcast_rows(bias.data_ptr(), N, bias.shape[0], out.data_ptr(), _stream(bias)),
+          "sphip_broadcast_rows")
+    return out
+
+
 # ------------------------------------------------------------------ dead-latent bookkeeping
 def mark_fired_(did_fire: Tensor, idx: Tensor) -> Tensor:
     _req(idx, "indices", torch.int64)

@@ -12,7 +12,7 @@ from typing import NamedTuple
 import torch
 from torch import Tensor, nn
 
-from . import ops, parallel
+from . import dead_decode, ops, parallel
 from .config import SparseCoderConfig
 from .fused_encoder import EncoderOutput, FusedEncoder
 from .utils import SparseDecode, decoder_impl
@@ -203,7 +203,12 @@ class SparseCoder(nn.Module):
             auxk_acts, auxk_indices = ops.topk(pre2, k_aux, keep_mask=dead_mask)      # :240-243
             # the gradient w.r.t. auxk_acts would flow into pre_acts, which the encoder
             # backward drops (fused_encoder.py:53,87) -- so it is never computed here.
-            e_hat = self.decode(auxk_acts, auxk_indices).reshape(e.shape)
+            if dead_decode.eligible(auxk_acts, self.W_dec, num_dead):
+                # few dead latents: the decode and its W_dec gradient as dense products
+                e_hat = dead_decode.DeadLatentDecode.apply(auxk_indices, auxk_acts, self.W_dec, self.b_dec,
+                                                           dead_mask, num_dead).reshape(e.shape)
+            else:
+                e_hat = self.decode(auxk_acts, auxk_indices).reshape(e.shape)
             auxk_sq, _ = ResidualLoss.apply(e_hat, e, total_variance)                  # :248-249
             auxk_loss = scale * auxk_sq
         else:

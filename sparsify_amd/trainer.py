@@ -438,6 +438,7 @@ class Trainer:
         from safetensors.torch import load_model
 
         device = self.device
+        parallel.wait_for_updates()
         train_state = torch.load(f"{path}/state.pt", map_location=device, weights_only=True)
         self.global_step = train_state["global_step"]
         for file in glob(f"{path}/rank_*_state.pt"):

@@ -140,6 +140,26 @@ def test_sparse_coder_fp32_vs_reference(device, name):
 
 @pytest.mark.parametrize("name", [n for n in golden_names("coder_") if "_bf16_" in n])
 def test_sparse_coder_bf16_vs_reference(device, name):
+    check_bf16_golden(name)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("coder_") if "_bf16_" in n and ("auxk" in n or "fewdead" in n)])
+def test_sparse_coder_bf16_auxk_dense_products_vs_reference(device, name, monkeypatch):
+    """The same goldens with the AuxK decode forced onto the dense matrix-core path
+    (sparsify_amd/dead_decode.py) instead of the row gather."""
+    from sparsify_amd import ops
+    monkeypatch.setenv("SPHIP_AUXK", "dense")
+    ops.timer.enabled = True
+    ops.timer.reset()
+    try:
+        check_bf16_golden(name)
+        assert len(ops.timer.events.get("sphip_gemm_bf16_f32acc", [])) == 6      # 3 forward + 3 backward
+    finally:
+        ops.timer.enabled = False
+        ops.timer.reset()
+
+
+def check_bf16_golden(name):
     """bf16 autocast. (a) the chosen top-k sets equal the reference's except at near ties of
     the k-th boundary (north_star rule); (b) on rows with identical sets, values and
     reconstructions match the reference; (c) losses and all gradients match the oracle

@@ -474,3 +474,76 @@ def test_center_cast(device):
             assert torch.equal(h.cpu(), ref.bfloat16())
     w = torch.randn(1000, 3)
     assert torch.equal(ops.cast_bf16(dev(w)).cpu(), w.bfloat16())
+
+
+# ------------------------------------------------------------------ AuxK as dense products
+@pytest.mark.parametrize("N,K,M", [(256, 64, 256), (300, 192, 520), (1000, 1024, 48), (77, 128, 4096)])
+def test_gemm_bf16_f32acc(device, N, K, M):
+    """fp32-output form of the 256x256 kernel: exact on integer operands, accumulate adds."""
+    from sparsify_amd import ops
+    torch.manual_seed(N + K + M)
+    xi = torch.randint(-4, 5, (N, K)).bfloat16()
+    Wi = torch.randint(-4, 5, (M, K)).bfloat16()
+    out = torch.full((N, M), float("nan"), device="cuda")
+    ops.gemm_bf16_f32acc(dev(xi), dev(Wi), out, accumulate=False)
+    exact = xi.float() @ Wi.float().T
+    assert torch.equal(out.cpu(), exact)
+    ops.gemm_bf16_f32acc(dev(xi), dev(Wi), out, accumulate=True)
+    assert torch.equal(out.cpu(), 2 * exact)
+    x = torch.randn(N, K).bfloat16()
+    W = torch.randn(M, K).bfloat16()
+    got = ops.gemm_bf16_f32acc(dev(x), dev(W), torch.empty(N, M, device="cuda"), accumulate=False).cpu()
+    torch.testing.assert_close(got.double(), x.double() @ W.double().T, rtol=1e-5, atol=2e-6 * K**0.5 * 4)
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16_f32acc(dev(x[:, :K - 8].contiguous()), dev(W[:, :K - 8].contiguous()), out, accumulate=False)
+
+
+def test_split_bf16_transposed_is_exact(device):
+    from sparsify_amd import ops
+    torch.manual_seed(0)
+    R, C = 333, 200
+    src = torch.randn(R, C) * torch.logspace(-6, 6, C)
+    src[5, 7] = 0.0
+    rows = torch.randperm(R)[:150]
+    for lst, n_rows, ldr in ((None, R, 384), (rows, 150, 192)):
+        parts = ops.split_bf16_transposed(dev(src), None if lst is None else dev(lst), n_rows, ldr).cpu()
+        want = (src if lst is None else src[lst]).T                                  # (C, n_rows)
+        total = parts[0].double() + parts[1].double() + parts[2].double()
+        assert torch.equal(total[:, :n_rows].float(), want)                         # 8 + 8 + 8 bits: exact
+        assert torch.equal(parts[0][:, :n_rows], want.bfloat16())
+        assert (parts[:, :, n_rows:] == 0).all()
+
+
+@pytest.mark.parametrize("N,D,M,k,n_dead", [(200, 48, 640, 24, 100), (256, 256, 2048, 128, 300), (130, 64, 512, 32, 32)])
+def test_dead_latent_decode_matches_gather(device, N, D, M, k, n_dead):
+    """DeadLatentDecode (dense products) against the row-gather decode on the same selection:
+    forward and both gradients agree to fp32 summation-order accuracy."""
+    from sparsify_amd import ops
+    from sparsify_amd.dead_decode import DeadLatentDecode
+    from sparsify_amd.utils import SparseDecode
+    torch.manual_seed(N + n_dead)
+    dead = torch.zeros(M, dtype=torch.bool)
+    dead[torch.randperm(M)[:n_dead]] = True
+    pre = torch.randn(N, M).relu().bfloat16()
+    kk = min(k, n_dead)
+    acts, idx = ops.topk(dev(pre), kk, keep_mask=dev(dead))
+    slot_of, dead_list = ops.dead_compact(dev(dead), n_dead)
+    assert torch.equal(dead_list.cpu(), dead.nonzero().flatten())
+    want_slots = torch.full((M,), -1, dtype=torch.int32)
+    want_slots[dead] = torch.arange(n_dead, dtype=torch.int32)
+    assert torch.equal(slot_of.cpu(), want_slots)
+    W = torch.randn(M, D)
+    b = torch.randn(D)
+    gy = dev(torch.randn(N, D))
+    res = {}
+    for name in ("gather", "dense"):
+        Wd, bd = dev(W).requires_grad_(True), dev(b).requires_grad_(True)
+        if name == "gather":
+            out = SparseDecode.apply(idx, Wd, acts.float(), bd)
+        else:
+            out = DeadLatentDecode.apply(idx, acts, Wd, bd, dev(dead), n_dead)
+        (out * gy).sum().backward()
+        res[name] = (out.detach().cpu(), Wd.grad.cpu(), bd.grad.cpu())
+    for a, b_, what in zip(res["dense"], res["gather"], ("decode", "W_dec.grad", "b_dec.grad")):
+        torch.testing.assert_close(a, b_, rtol=2e-5, atol=2e-5 * float(b_.abs().max()), msg=lambda m, w=what: f"{w}: {m}")
+    assert (res["dense"][1][~dead] == 0).all()
