@@ -104,3 +104,36 @@ def test_decoder_step_and_unit_norm_are_idempotent_where_they_should_be(state):
     ops.decoder_project_signsgd_(Wa, G, 1e-3, True)
     ops.decoder_project_signsgd_(Wb, Gp, 1e-3, True)                         # same step from the projected gradient
     assert float(((Wa - Wb).abs() > 1e-6).float().mean()) < 1e-3
+
+
+def test_auxk_dense_products_against_row_gather(state):
+    """AuxK decode of k_aux = D/2 = 2048 dead latents per token (10 % of the latents dead): the
+    dense matrix-core path (dead_decode.py) and the row-gather path give the same reconstruction
+    and the same W_dec / b_dec gradients up to fp32 summation order; rows of W_dec.grad that
+    belong to live latents stay exactly zero."""
+    from sparsify_amd import ops
+    from sparsify_amd.dead_decode import DeadLatentDecode
+    from sparsify_amd.utils import SparseDecode
+    g = state["gen"]
+    dead = torch.rand(M, device="cuda", generator=g) < 0.10
+    n_dead = int(dead.sum())
+    acts, idx = ops.topk(state["pre"], D // 2, keep_mask=dead)
+    assert bool(dead[idx].all())
+    W = state["W"]
+    bias = torch.randn(D, device="cuda", generator=g)
+    gy = torch.randn(N, D, device="cuda", generator=g)
+    res = {}
+    for name in ("dense", "gather"):
+        Wd, bd = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        if name == "dense":
+            out = DeadLatentDecode.apply(idx, acts, Wd, bd, dead, n_dead)
+        else:
+            out = SparseDecode.apply(idx, Wd, acts.float(), bd)
+        (out * gy).sum().backward()
+        res[name] = (out.detach(), Wd.grad, bd.grad)
+        del out
+    for a, b_, what in zip(res["dense"], res["gather"], ("decode", "W_dec.grad", "b_dec.grad")):
+        scale = float(b_.abs().max())
+        err = float((a - b_).abs().max())
+        assert err <= 2e-5 * scale, f"{what}: max abs difference {err:.3e} at scale {scale:.3e}"
+    assert not bool(res["dense"][1][~dead].any())
