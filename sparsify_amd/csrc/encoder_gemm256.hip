@@ -63,29 +63,11 @@ __device__ __forceinline__ void seg_barrier() {
 // OUTF: 0 = the encoder's epilogue (bias, ReLU, bf16, block maxima); 1 = store the fp32
 // accumulators as they are (P is float*); 2 = add them to the fp32 values already in P
 // (sphip_gemm_bf16_f32acc: products whose fp32 operand was split into bf16 terms).
-template <bool RELU, int DIAG = 0, int OUTF = 0>
-__global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* __restrict__ X,
-                                                                 const bf16_t* __restrict__ W,
-                                                                 const bf16_t* __restrict__ bias,
-                                                                 bf16_t* __restrict__ P, int N, int D, int M,
-                                                                 int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
-                                                                 int64_t ldp, int tilesT, unsigned* dbg = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
-    int tm, tn;
-    {
-        const unsigned nb = gridDim.x, bid = blockIdx.x;
-        const unsigned xcd = bid & 7, slot = bid >> 3;
-        const unsigned q = nb >> 3, r = nb & 7;
-        const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        const unsigned band = 8u * (unsigned)tilesN;
-        const unsigned g = L / band, within = L % band;
-        const unsigned first = g * 8;
-        const unsigned gsize = min((unsigned)tilesM - first, 8u);
-        tm = (int)(first + within % gsize);
-        tn = (int)(within / gsize);
-    }
+template <bool RELU, int DIAG, int OUTF>
+__device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ P, int N, int D,
+                                             int M, int tm, int tn, bf16_t* __restrict__ tile_max, int64_t ldp,
+                                             int tilesT, unsigned* dbg, char* smem) {
     const int m0 = (DIAG & 16) ? (tm & 1) * G_TILE : tm * G_TILE, n0 = (DIAG & 16) ? (tn & 1) * G_TILE : tn * G_TILE;
 
     const int tid = threadIdx.x;
@@ -411,6 +393,33 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
     }
 }
 
+// One workgroup per tile, or (gridDim.x < nTiles, a multiple of 8) a resident workgroup per CU
+// walking its XCD's tiles: virtual block vb = blockIdx.x + i * gridDim.x keeps vb & 7 = the XCD
+// the workgroup runs on, so the XCD-contiguous tile ranges below are the same in both forms.
+template <bool RELU, int DIAG = 0, int OUTF = 0>
+__global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* __restrict__ X,
+                                                                 const bf16_t* __restrict__ W,
+                                                                 const bf16_t* __restrict__ bias,
+                                                                 bf16_t* __restrict__ P, int N, int D, int M,
+                                                                 int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
+                                                                 int64_t ldp, int tilesT, unsigned* dbg = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned nb = (unsigned)tilesM * (unsigned)tilesN;
+    for (unsigned vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+        // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
+        const unsigned xcd = vb & 7, slot = vb >> 3;
+        const unsigned q = nb >> 3, r = nb & 7;
+        const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const unsigned band = 8u * (unsigned)tilesN;
+        const unsigned g = L / band, within = L % band;
+        const unsigned first = g * 8;
+        const unsigned gsize = min((unsigned)tilesM - first, 8u);
+        gemm256_tile<RELU, DIAG, OUTF>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
+                                       tile_max, ldp, tilesT, dbg, smem);
+        if (vb + gridDim.x < nb) __syncthreads();      // the next tile's staging overwrites the epilogue area
+    }
+}
+
 // Diagnostic builds (make DIAG=1): SPHIP_GEMM_DIAG selects a kernel with parts of the loop
 // removed (bit 0: no DMA, 1: no MFMA, 2: no ds_read, 3: no epilogue store, 4: every tile reads
 // tile 0/1 of each operand, 5: per-segment cycle stamps written to the SPHIP_GEMM_DBG
@@ -434,7 +443,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         }
         attr_set[relu ? 1 : 0] = true;
     }
-    dim3 grid((unsigned)nblocks), block(512);
+    // SPHIP_GEMM_PERSIST=n: n resident workgroups per CU-count of 256 walk the tiles (A/B switch)
+    const char* pers = getenv("SPHIP_GEMM_PERSIST");
+    const int64_t resident = pers ? 256ll * atoi(pers) : 0;
+    dim3 grid((unsigned)((resident > 0 && resident < nblocks) ? resident : nblocks)), block(512);
 #ifdef SPHIP_DIAG
     const char* dg = getenv("SPHIP_GEMM_DIAG");
     const int diag = dg ? atoi(dg) : 0;
