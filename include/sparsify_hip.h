@@ -226,6 +226,15 @@ int sphip_apply_signs(float* p, const int8_t* signs, int64_t n, float lr, void* 
                       void* stream);
 int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr,
                               int renorm, void* stream);
+/* The schedule-free step ("signum", see sphip_schedulefree_signsgd_step) with the exchanged
+ * signs in place of sign(g): sign(mean gradient), for decoder rows of the projected mean
+ * gradient (sphip_decoder_project_sign_i8 on the parameter y). Same arithmetic as the one-GPU
+ * kernels, so replicas and the single-GPU step agree bit for bit. */
+int sphip_schedulefree_apply_signs(float* p, float* z, const int8_t* signs, int64_t n, float lr,
+                                   float beta, float c, void* bf16_shadow, void* stream);
+int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const int8_t* signs, int64_t M,
+                                           int64_t D, float lr, float beta, float c, int renorm,
+                                           void* stream);
 
 /* trainer.py:422: did_fire[idx.flatten()] = True.  did_fire (M) uint8. */
 int sphip_mark_fired(const int64_t* idx, int64_t n_entries, int64_t M, uint8_t* did_fire,

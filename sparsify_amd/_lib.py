@@ -56,6 +56,8 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_gemm_bf16_f32acc": (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _P]),
     "sphip_scatter_rows": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_broadcast_rows": (_I, [_P, _L, _L, _P, _P]),
+    "sphip_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
+    "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),
     "sphip_apply_signs": (_I, [_P, _P, _L, _F, _P, _P]),

@@ -489,6 +489,79 @@ static inline unsigned flat_grid(int64_t work_items) {
     return (unsigned)b;
 }
 
+// The same two steps with the signs given (data-parallel sign exchange, parallel.SignExchange):
+// sign(mean gradient) -- for decoder rows of the projected mean gradient -- arrives as int8.
+__global__ __launch_bounds__(256) void sf_apply_signs_kernel(float* __restrict__ p, float* __restrict__ zb,
+                                                             const signed char* __restrict__ sg, int64_t n, float lr,
+                                                             float w_undo, float c, float w_y, bf16_t* __restrict__ shadow) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 y = *reinterpret_cast<const float4*>(p + i * 4);
+        float4 z = *reinterpret_cast<const float4*>(zb + i * 4);
+        const float4 t = unpack_signs(reinterpret_cast<const unsigned*>(sg)[i]);
+        sf_update(y.x, z.x, t.x, lr, w_undo, c, w_y);
+        sf_update(y.y, z.y, t.y, lr, w_undo, c, w_y);
+        sf_update(y.z, z.z, t.z, lr, w_undo, c, w_y);
+        sf_update(y.w, z.w, t.w, lr, w_undo, c, w_y);
+        *reinterpret_cast<float4*>(p + i * 4) = y;
+        *reinterpret_cast<float4*>(zb + i * 4) = z;
+        if (shadow != nullptr) *reinterpret_cast<uint2*>(shadow + i * 4) = pack_bf16x4(y);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float y = p[i], z = zb[i];
+        sf_update(y, z, (float)sg[i], lr, w_undo, c, w_y);
+        p[i] = y;
+        zb[i] = z;
+        if (shadow != nullptr) shadow[i] = f32_to_bf16(y);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void sf_decoder_apply_signs_kernel(float* __restrict__ W, float* __restrict__ Z,
+                                                                     const signed char* __restrict__ sg, int D, float lr,
+                                                                     float w_undo, float c, float w_y, int renorm,
+                                                                     float eps) {
+    __shared__ float red[16];
+    float* w = W + (int64_t)blockIdx.x * D;
+    float* zr = Z + (int64_t)blockIdx.x * D;
+    const signed char* t = sg + (int64_t)blockIdx.x * D;
+    float4 y[R], z[R];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        y[i] = z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < D) {
+            y[i] = *reinterpret_cast<const float4*>(w + col);
+            z[i] = *reinterpret_cast<const float4*>(zr + col);
+            const float4 u = unpack_signs(*reinterpret_cast<const unsigned*>(t + col));
+            sf_update(y[i].x, z[i].x, u.x, lr, w_undo, c, w_y);
+            sf_update(y[i].y, z[i].y, u.y, lr, w_undo, c, w_y);
+            sf_update(y[i].z, z[i].z, u.z, lr, w_undo, c, w_y);
+            sf_update(y[i].w, z[i].w, u.w, lr, w_undo, c, w_y);
+            ss = fmaf(y[i].x, y[i].x, ss); ss = fmaf(y[i].y, y[i].y, ss);
+            ss = fmaf(y[i].z, y[i].z, ss); ss = fmaf(y[i].w, y[i].w, ss);
+        }
+    }
+    if (renorm) {
+        const float denom = sqrtf(block_sum(ss, red)) + eps;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            y[i].x /= denom; y[i].y /= denom; y[i].z /= denom; y[i].w /= denom;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        if (col < D) {
+            *reinterpret_cast<float4*>(w + col) = y[i];
+            *reinterpret_cast<float4*>(zr + col) = z[i];
+        }
+    }
+}
+
 }  // namespace sphip
 
 extern "C" int sphip_center_cast(const void* x, int x_dtype, const float* b_dec, float* xc_f32, void* xc_bf16,
@@ -680,6 +753,40 @@ extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const
     else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     else hipLaunchKernelGGL((sf_decoder_kernel<4>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_schedulefree_apply_signs(float* p, float* z, const int8_t* signs, int64_t n, float lr, float beta,
+                                              float c, void* bf16_shadow, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(p && z && signs, SPHIP_EINVAL, "schedulefree_apply_signs: null pointer");
+    SPHIP_REQUIRE(n > 0 && beta > 0.f && beta <= 1.f, SPHIP_EINVAL, "schedulefree_apply_signs: bad n / beta");
+    SPHIP_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)signs & 3) == 0 &&
+                      ((uintptr_t)bf16_shadow & 7) == 0,
+                  SPHIP_EINVAL, "schedulefree_apply_signs: operands must be 16-byte aligned (signs: 4)");
+    hipLaunchKernelGGL(sf_apply_signs_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, z,
+                       (const signed char*)signs, n, lr, 1.f - 1.f / beta, c, 1.f - beta, (bf16_t*)bf16_shadow);
+    SPHIP_CHECK_LAUNCH("schedulefree_apply_signs");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const int8_t* signs, int64_t M, int64_t D,
+                                                      float lr, float beta, float c, int renorm, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && Z && signs, SPHIP_EINVAL, "decoder_schedulefree_apply_signs: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
+                  "decoder_schedulefree_apply_signs: bad shape / beta");
+    SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
+                      ((uintptr_t)signs & 3) == 0,
+                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_apply_signs: needs D %% 4 == 0, D <= 4096, aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)M), block(256);
+    const float wu = 1.f - 1.f / beta, wy = 1.f - beta;
+    const signed char* t = (const signed char*)signs;
+    if (D <= 1024) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<1>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<2>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<4>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    SPHIP_CHECK_LAUNCH("decoder_schedulefree_apply_signs");
     return SPHIP_OK;
 }
 

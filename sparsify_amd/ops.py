@@ -469,6 +469,35 @@ def decoder_apply_signs_(W: Tensor, signs: Tensor, lr: float, renorm: bool = Fal
     return W
 
 
+def schedulefree_apply_signs_(p: Tensor, z: Tensor, signs: Tensor, lr: float, beta: float, c: float,
+                              bf16_shadow: Tensor | None = None) -> Tensor:
+    """schedulefree_signsgd_step_ with int8 signs in place of sign(g)."""
+    _req(p, "param", torch.float32)
+    _req(z, "z", torch.float32)
+    _req(signs, "signs", torch.int8)
+    if signs.numel() != p.numel() or z.numel() != p.numel():
+        raise ValueError("schedulefree_apply_signs: size mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    check(_lib.load().sphip_schedulefree_apply_signs(p.data_ptr(), z.data_ptr(), signs.data_ptr(), p.numel(), float(lr),
+                                                    float(beta), float(c), _ptr(bf16_shadow), _stream(p)),
+          "sphip_schedulefree_apply_signs")
+    return p
+
+
+def decoder_schedulefree_apply_signs_(W: Tensor, Z: Tensor, signs: Tensor, lr: float, beta: float, c: float,
+                                      renorm: bool = False) -> Tensor:
+    _req(W, "W_dec", torch.float32, 2)
+    _req(Z, "z", torch.float32, 2)
+    _req(signs, "signs", torch.int8)
+    if signs.numel() != W.numel() or Z.shape != W.shape:
+        raise ValueError("decoder_schedulefree_apply_signs: size mismatch")
+    check(_lib.load().sphip_decoder_schedulefree_apply_signs(W.data_ptr(), Z.data_ptr(), signs.data_ptr(), W.shape[0],
+                                                            W.shape[1], float(lr), float(beta), float(c), int(renorm),
+                                                            _stream(W)), "sphip_decoder_schedulefree_apply_signs")
+    return W
+
+
 def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = False) -> Tensor:
     """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows."""
     _req(W, "W_dec", torch.float32, 2)

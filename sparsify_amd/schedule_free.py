@@ -79,6 +79,12 @@ class ScheduleFreeWrapper:
     def renormalised(self):
         return getattr(self.base, "renormalised", None)
 
+    def reduces(self, p) -> bool:
+        """True for parameters whose gradients this optimizer averages across ranks itself
+        (the base SignSGD's sign exchange); the trainer all-reduces the others."""
+        f = getattr(self.base, "reduces", None)
+        return bool(f and f(p))
+
     def _weights(self, group) -> float:
         lr = group["lr"] * group.get("d", 1.0)
         group["lr_max"] = max(lr, group["lr_max"])
@@ -88,7 +94,7 @@ class ScheduleFreeWrapper:
 
     def _fusable(self) -> bool:
         from .sign_sgd import SignSGD
-        if not isinstance(self.base, SignSGD) or getattr(self.base, "exchange_signs", False):
+        if not isinstance(self.base, SignSGD):
             return False
         for group in self.param_groups:
             for p in group["params"]:
@@ -104,6 +110,7 @@ class ScheduleFreeWrapper:
     def _fused_step(self):
         from . import ops
         from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
+        deferred = []
         for group in self.param_groups:
             c = self._weights(group)
             project, renorm = group.get("project_rows", False), group.get("renorm_rows", False)
@@ -114,6 +121,14 @@ class ScheduleFreeWrapper:
                 if "z" not in st:
                     st["z"] = p.detach().clone(memory_format=torch.preserve_format)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if self.reduces(p):
+                    # data parallel: the base optimizer's sign exchange feeds this step
+                    item = (p, st["z"], g, group["lr"], c, project, renorm)
+                    if self.base.overlap:
+                        deferred.append(item)
+                    else:
+                        self._exchange_step(*item, overlap=False)
+                    continue
                 if project:
                     ops.decoder_schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, renorm)
                     if renorm:
@@ -125,6 +140,26 @@ class ScheduleFreeWrapper:
                         register_bf16_shadow(p, shadow)
                 torch.autograd.graph.increment_version(p)
             group["k"] += 1
+        for item in sorted(deferred, key=lambda it: it[5]):       # encoder matrices first (sign_sgd.py)
+            self._exchange_step(*item, overlap=True)
+
+    def _exchange_step(self, p, z, g, lr, c, project: bool, renorm: bool, overlap: bool):
+        from . import ops
+        from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
+        w, beta = p.data, self.momentum
+        shadow = None if project else peek_bf16_shadow(p)
+        if project:
+            def apply_fn(signs, lo, hi):
+                ops.decoder_schedulefree_apply_signs_(w[lo:hi], z[lo:hi], signs, lr, beta, c, renorm)
+        else:
+            def apply_fn(signs, lo, hi):
+                ops.schedulefree_apply_signs_(w[lo:hi], z[lo:hi], signs, lr, beta, c,
+                                              None if shadow is None else shadow[lo:hi])
+        self.base.run_exchange(p, g, project, apply_fn, overlap)
+        if project and renorm:
+            self.base.renormalised.add(id(p))
+        if shadow is not None:
+            register_bf16_shadow(p, shadow)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -142,11 +177,14 @@ class ScheduleFreeWrapper:
                     if p.grad is not None:
                         ops.remove_parallel_grad_(p.grad, p.data)
                 group["project_rows"] = False
+        overlap, self.base.overlap = getattr(self.base, "overlap", False), False    # torch ops below read p at once
         try:
             self._generic_step()
         finally:
             for group in flagged:
                 group["project_rows"] = True
+            if hasattr(self.base, "overlap"):
+                self.base.overlap = overlap
         for group in flagged:
             if group.get("renorm_rows", False):
                 from . import ops

@@ -80,20 +80,32 @@ class SignSGD(Optimizer):
     def _exchange_step(self, p, g, lr, project: bool, renorm: bool, overlap: bool = False):
         """One large matrix under data parallelism: see parallel.SignExchange."""
         w = p.data
+        shadow = None if project else peek_bf16_shadow(p)
         if project:
-            def sign_fn(shard, lo, hi):
-                return ops.decoder_project_sign_i8(w[lo:hi], shard)
-
             def apply_fn(signs, lo, hi):
                 ops.decoder_apply_signs_(w[lo:hi], signs, lr, renorm)
         else:
-            shadow = peek_bf16_shadow(p)
-
-            def sign_fn(shard, lo, hi):
-                return ops.sign_i8(shard)
-
             def apply_fn(signs, lo, hi):
                 ops.apply_signs_(w[lo:hi], signs, lr, None if shadow is None else shadow[lo:hi])
+        self.run_exchange(p, g, project, apply_fn, overlap)
+        if project and renorm:
+            self.renormalised.add(id(p))
+        if shadow is not None:
+            register_bf16_shadow(p, shadow)
+
+    def run_exchange(self, p, g, project: bool, apply_fn, overlap: bool) -> None:
+        """Reduce-scatter the gradient, take the signs (decoder matrices: of the gradient
+        projected on the complement of the parameter's rows), all-gather them and hand them to
+        `apply_fn(signs, row_lo, row_hi)`; with `overlap` on the exchange stream, recording one
+        event per finished row block (parallel.set_pending). Also used by the schedule-free
+        wrapper, whose apply_fn is its own step."""
+        w = p.data
+        if project:
+            def sign_fn(shard, lo, hi):
+                return ops.decoder_project_sign_i8(w[lo:hi], shard)
+        else:
+            def sign_fn(shard, lo, hi):
+                return ops.sign_i8(shard)
         if overlap:
             cur = torch.cuda.current_stream(p.device)
             side = parallel.exchange_stream(p.device)
@@ -114,7 +126,3 @@ class SignSGD(Optimizer):
         else:
             parallel.SignExchange.step(g, sign_fn, apply_fn)
         torch.autograd.graph.increment_version(p)
-        if project and renorm:
-            self.renormalised.add(id(p))
-        if not project and shadow is not None:
-            register_bf16_shadow(p, shadow)

@@ -164,7 +164,8 @@ class Trainer:
                         pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
                 if cfg.optimizer == "signum":
-                    opt = ScheduleFreeWrapper(SignSGD(pgs), momentum=0.95)
+                    opt = ScheduleFreeWrapper(SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange),
+                                              momentum=0.95)
                     opt.train()
                     self.optimizers = [opt]
                 else:

@@ -23,6 +23,7 @@ def _free_port():
 
 
 MODES = ("allreduce", "exchange", "overlap")
+OPTIMIZERS = ("signsgd", "signum")       # plain SignSGD and the reference's default (schedule-free)
 
 
 def _worker(rank, world, port, ret):
@@ -34,9 +35,10 @@ def _worker(rank, world, port, ret):
         from sparsify_amd.trainer import SyntheticActivations, Trainer
         D, M, k, N, steps = 256, 4096, 16, 512, 4
         out = {}
-        for mode in MODES:
-            exchange, overlap = mode != "allreduce", mode == "overlap"
-            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"],
+        for mode in [(o, m) for o in OPTIMIZERS for m in MODES]:
+            optimizer, how = mode
+            exchange, overlap = how != "allreduce", how == "overlap"
+            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer=optimizer, hookpoints=["h0"],
                               save_dir="", save_every=10**9, wandb_log_frequency=1, exchange_signs=exchange,
                               overlap_exchange=overlap)
             src = SyntheticActivations(["h0"], D, N, steps, device="cuda", rank=rank)
@@ -69,18 +71,21 @@ def test_two_rank_trainer_sign_exchange_equals_all_reduce(device):
             pytest.fail("a rank did not finish (collective mismatch?)")
         assert p.exitcode == 0
     r0, r1 = ret[0], ret[1]
-    for mode in MODES:
+    for mode in r0.keys():
         for name in r0[mode]:
             if name == "fvu":
                 assert r0[mode]["fvu"] == pytest.approx(r1[mode]["fvu"], rel=1e-6)     # logged mean over ranks
             else:
                 assert torch.equal(r0[mode][name], r1[mode][name]), f"replicas diverged: {name} ({mode})"
     # two ranks: a + b is order independent, so every exchange sees the same mean gradient
-    for mode in MODES[1:]:
-        for name in r0["allreduce"]:
-            if name != "fvu":
-                assert torch.equal(r0["allreduce"][name], r0[mode][name]), f"{mode} != all-reduce: {name}"
-    assert r0["overlap"]["fvu"] < 1.0
+    for opt in OPTIMIZERS:
+        for how in MODES[1:]:
+            for name in r0[(opt, "allreduce")]:
+                if name != "fvu":
+                    assert torch.equal(r0[(opt, "allreduce")][name], r0[(opt, how)][name]), \
+                        f"{opt}/{how} != all-reduce: {name}"
+        assert r0[(opt, "overlap")]["fvu"] < 1.0
+    assert not torch.equal(r0[("signsgd", "overlap")]["W_dec"], r0[("signum", "overlap")]["W_dec"])
 
 
 def _rccl_one_rank(port, ret):
@@ -92,11 +97,11 @@ def _rccl_one_rank(port, ret):
         from sparsify_amd.trainer import SyntheticActivations, Trainer
         D, M, k, N, steps = 1024, 16384, 32, 4096, 6
         out = {}
-        for mode in MODES:
-            parallel.SignExchange.FORCE = mode != "allreduce"       # one rank: no exchange unless forced
-            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"],
+        for mode in [(o, m) for o in OPTIMIZERS for m in MODES]:
+            parallel.SignExchange.FORCE = mode[1] != "allreduce"    # one rank: no exchange unless forced
+            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer=mode[0], hookpoints=["h0"],
                               save_dir="", save_every=10**9, wandb_log_frequency=1, exchange_signs=True,
-                              overlap_exchange=mode == "overlap")
+                              overlap_exchange=mode[1] == "overlap")
             src = SyntheticActivations(["h0"], D, N, steps, device="cuda")
             torch.manual_seed(0)
             tr = Trainer(cfg, src, device="cuda")
@@ -130,10 +135,12 @@ def test_overlapped_exchange_over_rccl_one_rank(device):
         pytest.fail("the rank did not finish")
     assert proc.exitcode == 0
     out = ret[0]
-    for mode in MODES[1:]:
-        for name, ref in out["allreduce"].items():
-            if name not in ("fvu", "block_launches"):
-                assert torch.equal(ref, out[mode][name]), f"{mode}: {name} differs from the plain step"
-        assert out[mode]["fvu"] == out["allreduce"]["fvu"]
-    assert out["allreduce"]["block_launches"] == 0 and out["exchange"]["block_launches"] == 0
-    assert out["overlap"]["block_launches"] == 5 * 8           # steps 2..6, SignSGD.OVERLAP_BLOCKS each
+    for opt in OPTIMIZERS:
+        plain = out[(opt, "allreduce")]
+        for how in MODES[1:]:
+            for name, ref in plain.items():
+                if name not in ("fvu", "block_launches"):
+                    assert torch.equal(ref, out[(opt, how)][name]), f"{opt}/{how}: {name} differs from the plain step"
+            assert out[(opt, how)]["fvu"] == plain["fvu"]
+        assert plain["block_launches"] == 0 and out[(opt, "exchange")]["block_launches"] == 0
+        assert out[(opt, "overlap")]["block_launches"] == 5 * 8    # steps 2..6, SignSGD.OVERLAP_BLOCKS each
