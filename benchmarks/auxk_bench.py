@@ -12,7 +12,9 @@ from sparsify_amd.trainer import SyntheticActivations, Trainer  # noqa: E402
 
 N, D, M, k = int(os.environ.get("TOKENS", 16384)), 4096, 131072, 192
 dev = torch.device("cuda", 0)
-cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h"], auxk_alpha=1 / 32,
+MULTI = os.environ.get("MULTI_TOPK") == "1"        # multi-topk variant instead of AuxK (sparse_coder.py:256-262)
+cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, multi_topk=MULTI), optimizer="signsgd", hookpoints=["h"],
+                  auxk_alpha=0.0 if MULTI else 1 / 32,
                   dead_feature_threshold=10**6, save_every=10**9, wandb_log_frequency=10**9, save_dir="")
 steps, warm = 4, 2
 src = SyntheticActivations(["h"], D, N, steps + warm, device=dev)
@@ -32,6 +34,6 @@ for s in range(warm, warm + steps):
     tr.num_tokens_since_fired["h"][dead] = 10**7
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
-print(f"auxk step: {ms:.1f} ms  ({N / ms * 1e3:.0f} tokens/s)")
+print(f"{'multi-topk' if MULTI else 'auxk'} step: {ms:.1f} ms  ({N / ms * 1e3:.0f} tokens/s)")
 for name, v in ops.timer.summary().items():
     print(f"  {name:34s} {v['total_ms'] / steps:8.2f} ms/step in {v['calls'] / steps:.0f} calls")
