@@ -208,6 +208,23 @@ int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, 
                                             int64_t D, float lr, float beta, float c, int renorm,
                                             void* stream);
 
+/* The encoder weight gradient fused with its SignSGD step (fused_encoder.py:67-77 +
+ * sign_sgd.py:23): the segmented reduction of sphip_segmented_weight_grad (without dcoeff), but
+ * each finished row piece g updates the parameter in place, param -= lr * sign(g) (and the
+ * bf16 shadow, may be NULL), instead of being stored: the (M, D) gradient is never written nor
+ * read back by an optimizer pass. Same arithmetic as the two separate calls, bit for bit. Only
+ * valid where the gradient has no other consumer (one rank, no accumulation). Workspace as for
+ * sphip_segmented_weight_grad. sphip_segment_coeff_sums gives the bias gradient (sum of each
+ * latent's coefficients, fused_encoder.py:80-84) that the unfused kernel returns as gbias. */
+int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin,
+                                        const void* coeff, int coeff_dtype, const void* rows,
+                                        int rows_dtype, const float* row_shift, int64_t N, int64_t k,
+                                        int64_t M, int64_t D, float* param, float lr,
+                                        void* bf16_shadow, void* workspace, size_t workspace_bytes,
+                                        void* stream);
+int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                             int coeff_dtype, int64_t M, float* out, void* stream);
+
 /* Sign exchange for data-parallel SignSGD (DDP gradient exchange, trainer.py:457-468, done as
  * reduce-scatter of the fp32 gradients + all-gather of 1-byte signs instead of an all-reduce:
  * SignSGD.step, sign_sgd.py:23, only needs sign(mean gradient); 5/8 of the bytes on the wire).

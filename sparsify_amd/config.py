@@ -74,6 +74,10 @@ class TrainConfig(_Serializable):
     """(not in the reference) run that exchange and the updates it feeds on a second stream, under
     the next forward: the encoder GEMM follows the arriving row blocks (same update, same
     results; parallel.wait_for_updates() before reading parameters outside the Trainer)."""
+    fuse_encoder_update: bool = True
+    """(not in the reference) "signsgd" on one rank without gradient accumulation: apply the step of
+    `encoder.weight` inside its gradient kernel (same update; the (M, D) gradient is never
+    materialised, so `encoder.weight.grad` stays None)."""
     save_every: int = 1000
     save_best: bool = False
     finetune: str | None = None

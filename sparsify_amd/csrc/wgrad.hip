@@ -159,14 +159,19 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
     }
 }
 
-template <typename RT>
+// FUSE: gW is the PARAMETER; instead of storing the gradient row piece the kernel applies
+// SignSGD to it (sign_sgd.py:23: p -= lr * sign(g)) and refreshes the bf16 shadow, so the
+// (M, D) gradient is neither written nor read back by an optimizer pass
+// (sphip_segmented_weight_grad_signsgd).
+template <typename RT, bool FUSE = false>
 __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
                                                                const float* __restrict__ row_shift, FastDiv kdiv,
                                                                int64_t N, int M, int D, int blocks_per_slice,
-                                                               int num_slices) {
+                                                               int num_slices, float lr = 0.f,
+                                                               bf16_t* __restrict__ shadow = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
@@ -186,6 +191,15 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     float bsum = 0.f;
+    // FUSE: the parameter piece is requested now and used after the segment loop
+    float wold[FUSE ? C : 1];
+    if (FUSE && live) {
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col + c);
+            wold[c] = t.x, wold[c + 1] = t.y, wold[c + 2] = t.z, wold[c + 3] = t.w;
+        }
+    }
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
@@ -226,14 +240,50 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             for (int c = 0; c < C; ++c) acc[c] = fmaf(-bsum, row_shift[col + c], acc[c]);
         }
         float* o = gW + (int64_t)j * D + col;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        if (FUSE) {
+            unsigned short sh[C];
 #pragma unroll
-        for (int c = 0; c < C; c += 4) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4 t = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
-            __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o + c));
+            for (int c = 0; c < C; c += 4) {
+                f4 w = {wold[c], wold[c + 1], wold[c + 2], wold[c + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = acc[c + e];
+                    w[e] -= lr * (float)((g > 0.f) - (g < 0.f));
+                    sh[c + e] = f32_to_bf16(w[e]);
+                }
+                *reinterpret_cast<f4*>(o + c) = w;
+            }
+            if (shadow != nullptr) {
+                bf16_t* so = shadow + (int64_t)j * D + col;
+#pragma unroll
+                for (int c = 0; c < C; c += 4)
+                    *reinterpret_cast<uint2*>(so + c) = make_uint2((unsigned)sh[c] | ((unsigned)sh[c + 1] << 16),
+                                                                   (unsigned)sh[c + 2] | ((unsigned)sh[c + 3] << 16));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                f4 t = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o + c));
+            }
         }
     }
     if (gbias != nullptr && slice == 0 && sub == 0 && j < M) gbias[j] = bsum;
+}
+
+// gbias[j] = sum of the coefficients of latent j's segment, in segment order (the same chain as
+// bsum above): the bias gradient when the weight-gradient kernel runs fused with the optimizer
+template <typename CT>
+__global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __restrict__ perm,
+                                                            const int* __restrict__ seg_begin,
+                                                            const CT* __restrict__ coeff, int M,
+                                                            float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    float t = 0.f;
+    for (int p = seg_begin[j]; p < seg_begin[j + 1]; ++p) t += Elem<CT>::load(coeff, perm[p]);
+    out[j] = t;
 }
 
 
@@ -342,9 +392,10 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
     dcoeff[packed[p].x] = t;
 }
 
-template <typename RT>
+template <typename RT, bool FUSE = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
-                          float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s) {
+                          float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
+                          float lr = 0.f, bf16_t* shadow = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -358,8 +409,9 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
-                       (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices);
+    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
+                       (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
+                       shadow);
     return true;
 }
 
@@ -467,5 +519,57 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
         else launch_nv<bf16_t, false>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
     }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype,
+                                        int64_t M, float* out, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(coeff_dtype), SPHIP_EINVAL, "segment_coeff_sums: bad dtype");
+    SPHIP_REQUIRE(perm && seg_begin && coeff && out, SPHIP_EINVAL, "segment_coeff_sums: null pointer");
+    SPHIP_REQUIRE(M > 0 && M < (1ll << 31) - 256, SPHIP_EINVAL, "segment_coeff_sums: bad M");
+    dim3 grid((unsigned)cdiv(M, 256)), block(256);
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<float>), grid, block, 0, (hipStream_t)stream, perm, seg_begin, (const float*)coeff, (int)M, out);
+    else
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, perm, seg_begin, (const bf16_t*)coeff, (int)M, out);
+    SPHIP_CHECK_LAUNCH("segment_coeff_sums");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                                   int coeff_dtype, const void* rows, int rows_dtype,
+                                                   const float* row_shift, int64_t N, int64_t k, int64_t M, int64_t D,
+                                                   float* param, float lr, void* bf16_shadow, void* workspace,
+                                                   size_t workspace_bytes, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad_signsgd: bad dtype");
+    SPHIP_REQUIRE(perm && seg_begin && coeff && rows && param, SPHIP_EINVAL, "segmented_weight_grad_signsgd: null pointer");
+    SPHIP_REQUIRE(N > 0 && k > 0 && M > 0 && D > 0, SPHIP_EINVAL, "segmented_weight_grad_signsgd: empty shape");
+    SPHIP_REQUIRE(N * k < (1ll << 31) && M < (1ll << 31) - 4 && D < (1ll << 30), SPHIP_EUNSUPPORTED,
+                  "segmented_weight_grad_signsgd: shape too large");
+    SPHIP_REQUIRE(D % (rows_dtype == SPHIP_BF16 ? 8 : 4) == 0, SPHIP_EUNSUPPORTED,
+                  "segmented_weight_grad_signsgd: D=%lld must be a multiple of %d", (long long)D,
+                  rows_dtype == SPHIP_BF16 ? 8 : 4);
+    SPHIP_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)param & 15) == 0 && ((uintptr_t)row_shift & 15) == 0 &&
+                      ((uintptr_t)bf16_shadow & 7) == 0,
+                  SPHIP_EINVAL, "segmented_weight_grad_signsgd: rows/param/row_shift must be 16-byte aligned");
+    const size_t need = sphip_weight_grad_workspace_bytes(N, k, D);
+    SPHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need, SPHIP_EWORKSPACE,
+                  "segmented_weight_grad_signsgd: workspace %zu < %zu bytes", workspace_bytes, need);
+    SPHIP_REQUIRE(((uintptr_t)workspace & 255) == 0, SPHIP_EINVAL, "segmented_weight_grad_signsgd: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t E = N * k;
+    uint2* packed = (uint2*)workspace;
+    void* rows_sm = (char*)workspace + packed_bytes(N, k);
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
+    const bool done = rows_dtype == SPHIP_F32
+                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow)
+                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow);
+    SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
+    SPHIP_CHECK_LAUNCH("segmented_weight_grad_signsgd");
     return SPHIP_OK;
 }

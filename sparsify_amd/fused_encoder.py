@@ -65,6 +65,34 @@ def shadow_is_current(t: Tensor) -> bool:
     return hit is not None and hit[0] == (t._version, tuple(t.shape))
 
 
+# Optimizer-in-backward for the encoder matrix (sign_sgd.SignSGD.fuse_encoder_update): the
+# optimizer registers a Parameter with a callable returning its learning rate. For a registered
+# weight the backward applies p -= lr * sign(grad) inside the gradient kernel and returns no
+# gradient. Keyed by storage address, validated through a weak reference to the Parameter, so
+# an entry can never outlive its parameter and match another tensor at the same address.
+_inplace_signsgd: dict[int, tuple] = {}
+
+
+def register_inplace_signsgd(param: Tensor, lr_of) -> None:
+    import weakref
+    _inplace_signsgd[param.data_ptr()] = (weakref.ref(param), lr_of)
+
+
+def unregister_inplace_signsgd(param: Tensor) -> None:
+    _inplace_signsgd.pop(param.data_ptr(), None)
+
+
+def _inplace_lr(weight: Tensor):
+    hit = _inplace_signsgd.get(weight.data_ptr())
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if owner is None or owner.data_ptr() != weight.data_ptr() or owner.shape != weight.shape:
+        _inplace_signsgd.pop(weight.data_ptr(), None)
+        return None
+    return hit[1]
+
+
 def _autocast_bf16() -> bool:
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
@@ -153,7 +181,16 @@ class FusedEncoder(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         need_bdec = b_dec is not None and ctx.needs_input_grad[5]
 
-        if need_w or need_b or need_bdec:
+        lr_of = _inplace_lr(weight) if need_w else None
+        fuse = (lr_of is not None and weight.is_contiguous() and rows.shape[1] % 8 == 0
+                and gv.numel() < 64 * M)                      # long segments take the wide kernel
+        if fuse:
+            seg = ops.cached_segments(indices, M)
+            gb_full = ops.segment_coeff_sums(seg, gv)
+            grad_bias = gb_full if bias is not None else None
+            if need_bdec and not need_x:
+                grad_bdec = ops.vec_mat(gb_full, weight.detach(), -1.0)    # reads W before its update
+        elif need_w or need_b or need_bdec:
             seg = ops.cached_segments(indices, M)
             grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True, row_shift=shift)
             if bias is None:
@@ -165,9 +202,16 @@ class FusedEncoder(torch.autograd.Function):
             grad_input = gx.reshape(ctx.in_shape)
             if need_bdec:
                 grad_bdec = ops.colsum(gx, -1.0)
-        elif need_bdec:
+        elif need_bdec and grad_bdec is None:
             # sum_n grad_x[n,:] = gb^T W : one pass over W instead of an (N,k)-row gather
             grad_bdec = ops.vec_mat(gb_full, weight.detach(), -1.0)
+        if fuse:
+            # every reader of the old weight in this backward has been enqueued: update in place
+            shadow = peek_bf16_shadow(weight)
+            ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, lr_of(), shadow, row_shift=shift)
+            torch.autograd.graph.increment_version(weight)
+            if shadow is not None:
+                register_bf16_shadow(weight, shadow)
         return grad_input, grad_weight, grad_bias, None, None, grad_bdec
 
 

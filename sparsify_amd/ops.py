@@ -303,6 +303,47 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
     return gW, gb, dc
 
 
+def segment_coeff_sums(seg: LatentSegments, coeff: Tensor) -> Tensor:
+    """(M,) sums of each latent's coefficients: the encoder bias gradient (fused_encoder.py:80-84)."""
+    _req(coeff, "coeff", ndim=2)
+    if tuple(coeff.shape) != (seg.N, seg.k):
+        raise ValueError("segment_coeff_sums: shape mismatch")
+    out = torch.empty(seg.M, dtype=torch.float32, device=coeff.device)
+    check(_lib.load().sphip_segment_coeff_sums(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff),
+                                              seg.M, out.data_ptr(), _stream(coeff)), "sphip_segment_coeff_sums")
+    return out
+
+
+def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Tensor, param: Tensor, lr: float,
+                                   bf16_shadow: Tensor | None = None, row_shift: Tensor | None = None) -> Tensor:
+    """param -= lr * sign(weight gradient) without materialising the gradient (fused_encoder.py:67-77
+    + sign_sgd.py:23); the same arithmetic as segmented_weight_grad followed by signsgd_step_."""
+    _req(coeff, "coeff", ndim=2)
+    _req(rows, "rows", ndim=2)
+    _req(param, "param", torch.float32, 2)
+    N, k, M = seg.N, seg.k, seg.M
+    D = rows.shape[1]
+    if tuple(coeff.shape) != (N, k) or rows.shape[0] != N or tuple(param.shape) != (M, D):
+        raise ValueError("segmented_weight_grad_signsgd: shape mismatch")
+    if row_shift is not None:
+        _req(row_shift, "row_shift", torch.float32, 1)
+        if row_shift.shape[0] != D:
+            raise ValueError("segmented_weight_grad_signsgd: row_shift shape mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16, 2)
+        if bf16_shadow.shape != param.shape:
+            raise ValueError("segmented_weight_grad_signsgd: shadow shape mismatch")
+    lib = _lib.load()
+    ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
+    _ev = timer.start("sphip_segmented_weight_grad", rows)
+    check(lib.sphip_segmented_weight_grad_signsgd(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff),
+                                                  rows.data_ptr(), _dt(rows), _ptr(row_shift), N, k, M, D, param.data_ptr(),
+                                                  float(lr), _ptr(bf16_shadow), ws.data_ptr(), ws.numel(), _stream(rows)),
+          "sphip_segmented_weight_grad_signsgd")
+    timer.stop(_ev, rows)
+    return param
+
+
 # ------------------------------------------------------------------ loss pieces
 def _red_ws(t: Tensor, N: int, D: int) -> Tensor:
     return _workspace(t.device, _lib.load().sphip_reduce_workspace_bytes(N, D), "reduce")

@@ -35,6 +35,26 @@ class SignSGD(Optimizer):
         # the trainer consumes an id instead of normalising that decoder again
         self.renormalised: set[int] = set()
 
+    def fuse_encoder_update(self, weights) -> None:
+        """Optimizer-in-backward for encoder matrices (not in the reference): FusedEncoder's
+        backward applies this optimizer's step, p -= lr * sign(grad), inside the weight-gradient
+        kernel and leaves p.grad None, so step() skips them. Bit for bit the separate step; the
+        (M, D) gradient is never written. Only valid when nothing else consumes that gradient:
+        one rank, one backward per optimizer step, no clipping or logging of it."""
+        from .fused_encoder import register_inplace_signsgd
+        for group in self.param_groups:
+            for p in group["params"]:
+                if any(p is w for w in weights):
+                    if group.get("project_rows", False):
+                        raise ValueError("decoder matrices need the projected gradient: not fusable")
+                    register_inplace_signsgd(p, lambda g=group: g["lr"])
+
+    def unfuse_encoder_update(self) -> None:
+        from .fused_encoder import unregister_inplace_signsgd
+        for group in self.param_groups:
+            for p in group["params"]:
+                unregister_inplace_signsgd(p)
+
     def reduces(self, p) -> bool:
         return self.exchange_signs and parallel.SignExchange.eligible(p)
 

@@ -169,7 +169,13 @@ class Trainer:
                     opt.train()
                     self.optimizers = [opt]
                 else:
-                    self.optimizers = [SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange)]
+                    opt = SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange)
+                    self.optimizers = [opt]
+                    one_rank = not (dist.is_initialized() and dist.get_world_size() > 1)
+                    if (cfg.fuse_encoder_update and one_rank and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
+                            and cfg.loss_fn == "fvu" and self.device.type == "cuda"):
+                        opt.fuse_encoder_update([sae.encoder.weight for sae in self.saes.values()
+                                                 if not opt.reduces(sae.encoder.weight)])
                 self._fused_projection = project
             case other:
                 raise ValueError(f"Unknown optimizer '{other}'")

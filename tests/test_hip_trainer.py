@@ -101,6 +101,50 @@ def test_trainer_optimizers_reduce_fvu(device, optimizer, tmp_path):
     assert "auxk/h0" in tr.last_logged and "dead_pct/h0" in tr.last_logged
 
 
+@pytest.mark.parametrize("transcode,dtype", [(False, torch.bfloat16), (False, torch.float32), (True, torch.bfloat16)])
+def test_fused_encoder_update_equals_separate_step(device, transcode, dtype, monkeypatch):
+    """TrainConfig.fuse_encoder_update: the SignSGD step of encoder.weight applied inside the
+    weight-gradient kernel gives bit for bit the parameters of gradient + optimizer pass, and the
+    (M, D) gradient is never materialised."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig, ops
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N, steps = 128, 2048, 16, 1024, 6
+    batches = make_batches(steps, N, D, transcode)
+    gpu = [tuple(t.cuda().to(dtype) for t in b) if transcode else b.cuda().to(dtype) for b in batches]
+    res = {}
+    calls = {"fused": 0, "grads": 0}
+    fused_op, step_op = ops.segmented_weight_grad_signsgd_, ops.signsgd_step_
+
+    def count_fused(*a, **kw):
+        calls["fused"] += 1
+        return fused_op(*a, **kw)
+
+    def count_step(p, g, *a, **kw):
+        calls["grads"] += p.shape == (M, D)
+        return step_op(p, g, *a, **kw)
+
+    monkeypatch.setattr(ops, "segmented_weight_grad_signsgd_", count_fused)
+    monkeypatch.setattr(ops, "signsgd_step_", count_step)
+    for fuse in (False, True):
+        cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, transcode=transcode), optimizer="signsgd",
+                          save_dir="", save_every=10**9, wandb_log_frequency=1, fuse_encoder_update=fuse)
+        torch.manual_seed(0)
+        tr = Trainer(cfg, ListSource(gpu, D), device="cuda")
+        fvus = []
+        calls["fused"] = calls["grads"] = 0
+        for b in gpu:
+            tr.train_micro_batch({"h0": b})
+            fvus.append(tr.last_logged["fvu/h0"])
+        # fused: every step updates encoder.weight inside the gradient kernel and no (M, D) gradient
+        # reaches the optimizer (a transcoder's W_dec, not projected, still takes the plain step)
+        assert calls["fused"] == (steps if fuse else 0)
+        assert calls["grads"] == (steps if transcode else 0) + (0 if fuse else steps)
+        res[fuse] = ({n: p.detach().clone() for n, p in tr.saes["h0"].named_parameters()}, fvus)
+    for name, ref in res[False][0].items():
+        assert torch.equal(ref, res[True][0][name]), name
+    assert res[False][1] == res[True][1]
+
+
 def test_trainer_save_best(device, tmp_path):
     """trainer.py:540-544, 701-724: at every save_every-th step the per-coder best FVU is
     tracked and the coder written under {run}/best/{name}; a worse loss overwrites nothing."""
