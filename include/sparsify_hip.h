@@ -73,6 +73,11 @@ int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* 
  * data-parallel trainer can start the forward on the latents whose averaged update
  * (trainer.py:457-468) has arrived while the rest is still on the wire. bf16 only,
  * M_block % SPHIP_TOPK_TILE == 0, ld_pre % 8 == 0, D % 64 == 0. */
+/* 1 if sphip_encoder_preacts computes this shape with the 256x256 kernel (the one
+ * sphip_encoder_preacts_block always uses), 0 for the 128x128 kernel. The two round a few
+ * outputs differently (different fp32 summation order), so a caller that recomputes a subset of
+ * the latents and needs the very same values (the compact AuxK selection) asks which one ran. */
+int sphip_encoder_preacts_uses_tile256(int dtype, int64_t N, int64_t D, int64_t M);
 int sphip_encoder_preacts_block(const void* x, const void* W, const void* bias, void* pre,
                                 void* tile_max, int dtype, int64_t N, int64_t D, int64_t M_block,
                                 int64_t ld_pre, int64_t tiles_total, int relu, void* stream);
@@ -284,7 +289,14 @@ int sphip_dead_mask(const int64_t* counts, int64_t M, int64_t threshold, uint8_t
  *   sphip_gemm_bf16_f32acc:      out (N, ld_out) fp32 (+)= x (N,K) W (M,K)^T, bf16 operands, fp32
  *                                accumulate; accumulate != 0 adds to what out holds. K % 64 == 0
  *   sphip_scatter_rows:          dst (M, D) = 0; dst[row_list[r], :] = src[r, :] for r < R
- *   sphip_broadcast_rows:        out[n, :] = bias (the `+ b_dec` the products are added to) */
+ *   sphip_broadcast_rows:        out[n, :] = bias (the `+ b_dec` the products are added to)
+ *   sphip_gather_rows_bf16:      dst (rows_out, D) bf16 = src[row_list[r], :] for r < R, zero rows
+ *                                after: the dead latents' encoder rows / bias, from which
+ *                                sphip_encoder_preacts recomputes their pre-activations as a compact
+ *                                (N, rows_out) matrix (same kernel, same values), so that the AuxK
+ *                                top-k (sparse_coder.py:240-243) reads n_dead instead of M columns;
+ *                                its indices are then slots: pass slot_of = NULL to
+ *                                sphip_dead_scatter_acts */
 int sphip_dead_compact(const uint8_t* mask, int64_t M, int32_t* slot_of, int64_t* dead_list,
                        int64_t list_capacity, void* stream);
 int sphip_dead_scatter_acts(const int64_t* idx, const void* acts_bf16, const int32_t* slot_of,
@@ -297,6 +309,8 @@ int sphip_gemm_bf16_f32acc(const void* x, const void* W, float* out, int64_t N, 
 int sphip_scatter_rows(const float* src, const int64_t* row_list, int64_t R, int64_t D, int64_t M,
                        float* dst, void* stream);
 int sphip_broadcast_rows(const float* bias, int64_t N, int64_t D, float* out, void* stream);
+int sphip_gather_rows_bf16(const void* src, const int64_t* row_list, int64_t R, int64_t rows_out,
+                           int64_t D, void* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_center_cast": (_I, [_P, _I, _P, _P, _P, _L, _L, _P]),
     "sphip_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "sphip_encoder_preacts": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P]),
+    "sphip_encoder_preacts_uses_tile256": (_I, [_I, _L, _L, _L]),
     "sphip_encoder_preacts_block": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _P]),
     "sphip_topk": (_I, [_P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_groupmax": (_I, [_P, _I, _L, _L, _L, _P, _P, _P]),
@@ -56,6 +57,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_gemm_bf16_f32acc": (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _P]),
     "sphip_scatter_rows": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_broadcast_rows": (_I, [_P, _L, _L, _P, _P]),
+    "sphip_gather_rows_bf16": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
     "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P]),
     "sphip_segmented_weight_grad_signsgd": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _F, _P, _P, _Z, _P]),

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void dead_scatter_kernel(const int64_t* __rest
     if (i >= total) return;
     const int64_t j = idx[i];
     if (j < 0 || j >= M) return;
-    const int s = slot_of[j];
+    const int s = slot_of != nullptr ? slot_of[j] : (int)j;     // no map: the indices are slots already
     if (s < 0) return;
     const int64_t n = i / k;
     const bf16_t a = acts[i];
@@ -119,6 +119,27 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     reinterpret_cast<float4*>(dst)[list[r] * D4 + c] = reinterpret_cast<const float4*>(src)[i];
 }
 
+// dst row r = src row list[r] for r < R, zero for R <= r < rows_out; rows of `units` 2-byte
+// elements (the bf16 shadow of the encoder rows / bias of the dead latents)
+__global__ __launch_bounds__(256) void gather_rows_u16_kernel(const bf16_t* __restrict__ src,
+                                                              const int64_t* __restrict__ list, int64_t R,
+                                                              int64_t rows_out, int units, bf16_t* __restrict__ dst) {
+    const int64_t r = blockIdx.x;
+    if (r >= rows_out) return;
+    bf16_t* d = dst + r * units;
+    if (r < R) {
+        const bf16_t* s = src + list[r] * units;
+        if ((units & 7) == 0) {
+            for (int c = threadIdx.x * 8; c < units; c += 256 * 8)
+                *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(s + c);
+        } else {
+            for (int c = threadIdx.x; c < units; c += 256) d[c] = s[c];
+        }
+    } else {
+        for (int c = threadIdx.x; c < units; c += 256) d[c] = 0;
+    }
+}
+
 // out[n][:] = bias (the fp32 products are then accumulated on top)
 __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ bias, int64_t total4, int D4,
                                                              float* __restrict__ out) {
@@ -148,7 +169,7 @@ extern "C" int sphip_dead_compact(const uint8_t* mask, int64_t M, int32_t* slot_
 extern "C" int sphip_dead_scatter_acts(const int64_t* idx, const void* acts_bf16, const int32_t* slot_of, int64_t N,
                                        int64_t k, int64_t M, int64_t Kd, int64_t ldA, int64_t ldT, void* A, void* At,
                                        void* stream) {
-    SPHIP_REQUIRE(idx && acts_bf16 && slot_of && A && At, SPHIP_EINVAL, "dead_scatter_acts: null pointer");
+    SPHIP_REQUIRE(idx && acts_bf16 && A && At, SPHIP_EINVAL, "dead_scatter_acts: null pointer");
     SPHIP_REQUIRE(N > 0 && k > 0 && M > 0 && Kd > 0 && ldA >= Kd && ldT >= N && k < (1ll << 31) && M < (1ll << 31),
                   SPHIP_EINVAL, "dead_scatter_acts: bad sizes N=%lld k=%lld Kd=%lld ldA=%lld ldT=%lld", (long long)N,
                   (long long)k, (long long)Kd, (long long)ldA, (long long)ldT);
@@ -217,5 +238,18 @@ extern "C" int sphip_broadcast_rows(const float* bias, int64_t N, int64_t D, flo
     hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, bias,
                        total4, (int)(D / 4), out);
     SPHIP_CHECK_LAUNCH("broadcast_rows");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_gather_rows_bf16(const void* src, const int64_t* row_list, int64_t R, int64_t rows_out, int64_t D,
+                                      void* dst, void* stream) {
+    SPHIP_REQUIRE(src && row_list && dst, SPHIP_EINVAL, "gather_rows_bf16: null pointer");
+    SPHIP_REQUIRE(R > 0 && rows_out >= R && rows_out < (1ll << 31) && D > 0 && D < (1ll << 31), SPHIP_EINVAL,
+                  "gather_rows_bf16: bad sizes R=%lld rows_out=%lld D=%lld", (long long)R, (long long)rows_out, (long long)D);
+    SPHIP_REQUIRE((D & 7) != 0 || ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, SPHIP_EINVAL,
+                  "gather_rows_bf16: rows of a multiple of 8 elements must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_u16_kernel, dim3((unsigned)rows_out), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, row_list, R, rows_out, (int)D, (bf16_t*)dst);
+    SPHIP_CHECK_LAUNCH("gather_rows_bf16");
     return SPHIP_OK;
 }

@@ -238,6 +238,14 @@ static int launch_tile_max(const void* pre, void* tile_max, int64_t N, int64_t M
 
 }  // namespace sphip
 
+extern "C" int sphip_encoder_preacts_uses_tile256(int dtype, int64_t N, int64_t D, int64_t M) {
+    if (dtype != SPHIP_BF16 || D % 64 != 0 || D < 64) return 0;
+    // large shapes: 256x256 LDS-DMA kernel (needs >= one workgroup per CU to pay off);
+    // SPHIP_GEMM=128|256 forces a kernel (tests).
+    const char* force = getenv("SPHIP_GEMM");
+    return (force ? (force[0] == '2') : (sphip::cdiv(M, 256) * sphip::cdiv(N, 256) >= 256)) ? 1 : 0;
+}
+
 extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* bias, void* pre, void* tile_max,
                                      int dtype, int64_t N, int64_t D, int64_t M, int relu, void* stream) {
     using namespace sphip;
@@ -256,8 +264,7 @@ extern "C" int sphip_encoder_preacts(const void* x, const void* W, const void* b
     if (dtype == SPHIP_BF16) {
         // large shapes: 256x256 LDS-DMA kernel (needs >= one workgroup per CU to pay off);
         // SPHIP_GEMM=128|256 forces a kernel (tests).
-        const char* force = getenv("SPHIP_GEMM");
-        const bool want256 = force ? (force[0] == '2') : (cdiv(M, 256) * cdiv(N, 256) >= 256);
+        const bool want256 = sphip_encoder_preacts_uses_tile256(dtype, N, D, M) != 0;
         int status = SPHIP_OK;
         if (want256 && launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M, M, cdiv(M, 128), relu, s, &status)) return status;
         status = launch_gemm<bf16_t>(x, W, bias, pre, N, D, M, relu, s);

@@ -24,28 +24,30 @@ DENSE_RATIO = 24
 MIN_ENTRIES = 1 << 22
 
 
-def eligible(acts: Tensor, W_dec: Tensor, num_dead: int) -> bool:
+def eligible(pre_acts: Tensor, k_aux: int, W_dec: Tensor, num_dead: int) -> bool:
+    """pre_acts: the (N, M) pre-activations the AuxK selection runs on (bf16 under autocast)."""
     force = os.environ.get("SPHIP_AUXK")
-    if force == "gather" or acts.dtype != torch.bfloat16 or W_dec.dtype != torch.float32 or W_dec.shape[1] % 4:
+    if (force == "gather" or pre_acts.dtype != torch.bfloat16 or W_dec is None or W_dec.dtype != torch.float32
+            or W_dec.shape[1] % 8):
         return False
     if force == "dense":
         return True
-    k_aux = acts.shape[-1]
-    return num_dead <= DENSE_RATIO * k_aux and acts.numel() >= MIN_ENTRIES
+    return num_dead <= DENSE_RATIO * k_aux and pre_acts.shape[0] * k_aux >= MIN_ENTRIES
 
 
 class DeadLatentDecode(torch.autograd.Function):
     """decode(auxk_acts, auxk_indices) for indices that all lie on dead latents; gradients for
     W_dec and b_dec only (the gradient w.r.t. the activations would flow into pre_acts, which
-    the encoder backward drops, fused_encoder.py:53,87)."""
+    the encoder backward drops, fused_encoder.py:53,87). `dead_list` / `slot_of` come from
+    ops.dead_compact; slot_of None means the indices already are slots (auxk_select_compact)."""
 
     @staticmethod
-    def forward(ctx, indices: Tensor, acts: Tensor, W_dec: Tensor, b_dec: Tensor, dead_mask: Tensor, num_dead: int):
+    def forward(ctx, indices: Tensor, acts: Tensor, W_dec: Tensor, b_dec: Tensor, dead_list: Tensor,
+                slot_of: Tensor | None, num_dead: int):
         parallel.wait_for(W_dec)
         N = indices.shape[0]
         M, D = W_dec.shape
         Kd = -(-num_dead // 64) * 64
-        slot_of, dead_list = ops.dead_compact(dead_mask, num_dead)
         A, At = ops.dead_scatter_acts(indices, acts.contiguous(), slot_of, Kd)
         w_parts = ops.split_bf16_transposed(W_dec.detach(), dead_list, num_dead, Kd)      # 3 x (D, Kd)
         out = ops.broadcast_rows(b_dec.detach(), N)
@@ -59,7 +61,7 @@ class DeadLatentDecode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         At, dead_list = ctx.saved_tensors
         N, M, D, num_dead = ctx.dims
         g = g.reshape(N, D).contiguous().float()
@@ -72,4 +74,25 @@ class DeadLatentDecode(torch.autograd.Function):
             gW = ops.scatter_rows(G, dead_list, num_dead, M)
         if ctx.needs_input_grad[3]:
             gb = ops.colsum(g, 1.0)
-        return None, None, gW, gb, None, None
+        return None, None, gW, gb, None, None, None
+
+
+def auxk_select_compact(x_low: Tensor, W_low: Tensor, b_low: Tensor | None, dead_list: Tensor, num_dead: int, k_aux: int,
+                        M: int | None = None):
+    """torch.where(dead_mask, pre_acts, -inf).topk(k_aux) (sparse_coder.py:240-243) without the
+    sweep over all M columns: the dead latents' pre-activations are recomputed as a compact
+    (N, n_dead) matrix from their gathered encoder rows -- the same GEMM kernel, hence the same
+    values -- and the top-k runs on that. Returns (acts, slots): slots index dead_list."""
+    rows_out = -(-num_dead // ops.TOPK_TILE) * ops.TOPK_TILE      # padding columns: zero rows, relu -> 0,
+    Wd = ops.gather_rows_bf16(W_low, dead_list, num_dead, rows_out)   # placed last, never needed (k_aux <= n_dead)
+    bd = None if b_low is None else ops.gather_rows_bf16(b_low, dead_list, num_dead, rows_out)
+    # the same GEMM kernel as the full-width product used (its two tile shapes round a few
+    # outputs differently): the block entry point always runs the 256x256 one
+    N, D = x_low.shape
+    if ops.encoder_preacts_uses_tile256(N, D, W_low.shape[0] if M is None else M):
+        pre_d = torch.empty(N, rows_out, dtype=torch.bfloat16, device=x_low.device)
+        tmax = torch.empty(-(-N // 64), rows_out // ops.TOPK_TILE, 64, dtype=torch.bfloat16, device=x_low.device)
+        ops.encoder_preacts_block(x_low, Wd, bd, pre_d, tmax, 0, rows_out)
+    else:
+        pre_d, tmax = ops.encoder_preacts(x_low, Wd, bd, want_tile_max=True)
+    return ops.topk(pre_d, k_aux, tile_max=tmax)

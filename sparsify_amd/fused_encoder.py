@@ -97,6 +97,13 @@ def _autocast_bf16() -> bool:
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
+def low_precision_input(x2: Tensor, b_dec: Tensor | None) -> Tensor:
+    """The bf16 operand FusedEncoder.forward feeds the GEMM: bf16(x - b_dec), or bf16(x)."""
+    if b_dec is None and x2.dtype == torch.bfloat16:
+        return x2
+    return ops.center_cast(x2, None if b_dec is None else b_dec.detach().contiguous(), want_f32=False, want_bf16=True)[1]
+
+
 class FusedEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight, bias, k: int, activation: Literal["groupmax", "topk"], b_dec=None):

@@ -137,6 +137,11 @@ def encoder_preacts(x: Tensor, W: Tensor, bias: Tensor | None, relu: bool = True
     return (pre, tmax) if want_tile_max else pre
 
 
+def encoder_preacts_uses_tile256(N: int, D: int, M: int) -> bool:
+    """Whether encoder_preacts computes a bf16 (N, D) x (M, D) product with the 256x256 kernel."""
+    return bool(_lib.load().sphip_encoder_preacts_uses_tile256(BF16, N, D, M))
+
+
 def encoder_preacts_block(x: Tensor, W: Tensor, bias: Tensor | None, pre: Tensor, tile_max: Tensor | None,
                           lo: int, hi: int, relu: bool = True) -> None:
     """Fills pre[:, lo:hi] (and the matching blocks of tile_max) from rows lo:hi of W: one latent
@@ -561,18 +566,34 @@ def dead_compact(dead_mask: Tensor, num_dead: int):
     return slot_of, dead_list
 
 
-def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor, Kd: int):
-    """Selected activations as dense bf16 matrices A (N, Kd) and A^T (Kd, ceil64(N))."""
+def gather_rows_bf16(src: Tensor, row_list: Tensor, R: int, rows_out: int) -> Tensor:
+    """(rows_out, D) bf16: rows row_list[:R] of src, zero rows after (src may be 1-D: D = 1)."""
+    _req(src, "src", torch.bfloat16)
+    _req(row_list, "row_list", torch.int64, 1)
+    if row_list.shape[0] < R or src.ndim not in (1, 2):
+        raise ValueError("gather_rows_bf16: bad arguments")
+    D = 1 if src.ndim == 1 else src.shape[1]
+    dst = torch.empty((rows_out,) if src.ndim == 1 else (rows_out, D), dtype=torch.bfloat16, device=src.device)
+    check(_lib.load().sphip_gather_rows_bf16(src.data_ptr(), row_list.data_ptr(), R, rows_out, D, dst.data_ptr(),
+                                            _stream(src)), "sphip_gather_rows_bf16")
+    return dst
+
+
+def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor | None, Kd: int):
+    """Selected activations as dense bf16 matrices A (N, Kd) and A^T (Kd, ceil64(N)).
+    slot_of None: the indices are slots of the compact dead-latent numbering already."""
     _req(idx, "indices", torch.int64, 2)
     _req(acts, "acts", torch.bfloat16, 2)
-    _req(slot_of, "slot_of", torch.int32, 1)
+    if slot_of is not None:
+        _req(slot_of, "slot_of", torch.int32, 1)
     if acts.shape != idx.shape:
         raise ValueError("dead_scatter_acts: shape mismatch")
     N, k = idx.shape
     ldT = -(-N // 64) * 64
     A = torch.empty(N, Kd, dtype=torch.bfloat16, device=idx.device)
     At = torch.empty(Kd, ldT, dtype=torch.bfloat16, device=idx.device)
-    check(_lib.load().sphip_dead_scatter_acts(idx.data_ptr(), acts.data_ptr(), slot_of.data_ptr(), N, k, slot_of.shape[0],
+    check(_lib.load().sphip_dead_scatter_acts(idx.data_ptr(), acts.data_ptr(), _ptr(slot_of), N, k,
+                                             Kd if slot_of is None else slot_of.shape[0],
                                              Kd, Kd, ldT, A.data_ptr(), At.data_ptr(), _stream(idx)),
           "sphip_dead_scatter_acts")
     return A, At

@@ -14,7 +14,7 @@ from torch import Tensor, nn
 
 from . import dead_decode, ops, parallel
 from .config import SparseCoderConfig
-from .fused_encoder import EncoderOutput, FusedEncoder
+from .fused_encoder import EncoderOutput, FusedEncoder, bf16_shadow, low_precision_input
 from .utils import SparseDecode, decoder_impl
 
 
@@ -200,14 +200,20 @@ class SparseCoder(nn.Module):
             scale = min(num_dead / k_aux, 1.0)
             k_aux = min(k_aux, num_dead)
             pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
-            auxk_acts, auxk_indices = ops.topk(pre2, k_aux, keep_mask=dead_mask)      # :240-243
             # the gradient w.r.t. auxk_acts would flow into pre_acts, which the encoder
             # backward drops (fused_encoder.py:53,87) -- so it is never computed here.
-            if dead_decode.eligible(auxk_acts, self.W_dec, num_dead):
-                # few dead latents: the decode and its W_dec gradient as dense products
-                e_hat = dead_decode.DeadLatentDecode.apply(auxk_indices, auxk_acts, self.W_dec, self.b_dec,
-                                                           dead_mask, num_dead).reshape(e.shape)
+            if dead_decode.eligible(pre2, k_aux, self.W_dec, num_dead):
+                # few dead latents: selection on their recomputed, compact pre-activations and
+                # the decode + W_dec gradient as dense products (dead_decode.py)
+                slot_of, dead_list = ops.dead_compact(dead_mask, num_dead)
+                x_low = low_precision_input(x.reshape(-1, x.shape[-1]).contiguous(),
+                                            None if self.cfg.transcode else self.b_dec)
+                auxk_acts, slots = dead_decode.auxk_select_compact(
+                    x_low, bf16_shadow(self.encoder.weight), bf16_shadow(self.encoder.bias), dead_list, num_dead, k_aux)
+                e_hat = dead_decode.DeadLatentDecode.apply(slots, auxk_acts, self.W_dec, self.b_dec, dead_list, None,
+                                                           num_dead).reshape(e.shape)
             else:
+                auxk_acts, auxk_indices = ops.topk(pre2, k_aux, keep_mask=dead_mask)      # :240-243
                 e_hat = self.decode(auxk_acts, auxk_indices).reshape(e.shape)
             auxk_sq, _ = ResidualLoss.apply(e_hat, e, total_variance)                  # :248-249
             auxk_loss = scale * auxk_sq

@@ -119,6 +119,12 @@ def test_auxk_dense_products_against_row_gather(state):
     n_dead = int(dead.sum())
     acts, idx = ops.topk(state["pre"], D // 2, keep_mask=dead)
     assert bool(dead[idx].all())
+    slot_of, dead_list = ops.dead_compact(dead, n_dead)
+    # the compact selection (recomputed pre-activations of the dead latents) picks the same set
+    from sparsify_amd.dead_decode import auxk_select_compact
+    c_acts, c_slots = auxk_select_compact(state["x"], state["Wb"], None, dead_list, n_dead, D // 2)
+    assert torch.equal(dead_list[c_slots].sort(-1).values, idx.sort(-1).values)
+    assert torch.equal(c_acts.float().sort(-1).values, acts.float().sort(-1).values)
     W = state["W"]
     bias = torch.randn(D, device="cuda", generator=g)
     gy = torch.randn(N, D, device="cuda", generator=g)
@@ -126,7 +132,7 @@ def test_auxk_dense_products_against_row_gather(state):
     for name in ("dense", "gather"):
         Wd, bd = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
         if name == "dense":
-            out = DeadLatentDecode.apply(idx, acts, Wd, bd, dead, n_dead)
+            out = DeadLatentDecode.apply(c_slots, c_acts, Wd, bd, dead_list, None, n_dead)
         else:
             out = SparseDecode.apply(idx, Wd, acts.float(), bd)
         (out * gy).sum().backward()

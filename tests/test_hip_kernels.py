@@ -541,9 +541,32 @@ def test_dead_latent_decode_matches_gather(device, N, D, M, k, n_dead):
         if name == "gather":
             out = SparseDecode.apply(idx, Wd, acts.float(), bd)
         else:
-            out = DeadLatentDecode.apply(idx, acts, Wd, bd, dev(dead), n_dead)
+            out = DeadLatentDecode.apply(idx, acts, Wd, bd, dead_list, slot_of, n_dead)
         (out * gy).sum().backward()
         res[name] = (out.detach().cpu(), Wd.grad.cpu(), bd.grad.cpu())
     for a, b_, what in zip(res["dense"], res["gather"], ("decode", "W_dec.grad", "b_dec.grad")):
         torch.testing.assert_close(a, b_, rtol=2e-5, atol=2e-5 * float(b_.abs().max()), msg=lambda m, w=what: f"{w}: {m}")
     assert (res["dense"][1][~dead] == 0).all()
+
+
+@pytest.mark.parametrize("N,D,M,n_dead,k", [(512, 256, 32768, 3000, 128), (300, 64, 1024, 200, 32), (256, 128, 2048, 77, 77)])
+def test_auxk_compact_selection_equals_masked_topk(device, N, D, M, n_dead, k):
+    """auxk_select_compact recomputes the dead latents' pre-activations as a compact matrix and
+    selects there: the same latents with the same values as the masked top-k over the full row
+    (sparse_coder.py:240-243), for the 256-tile and the 128-tile GEMM alike."""
+    from sparsify_amd import ops
+    from sparsify_amd.dead_decode import auxk_select_compact
+    torch.manual_seed(M + n_dead)
+    x = dev(torch.randn(N, D).bfloat16())
+    W = dev((torch.randn(M, D) / D**0.5).bfloat16())
+    b = dev((torch.randn(M) * 0.1).bfloat16())
+    dead = torch.zeros(M, dtype=torch.bool)
+    dead[torch.randperm(M)[:n_dead]] = True
+    pre = ops.encoder_preacts(x, W, b)
+    want_acts, want_idx = ops.topk(pre, k, keep_mask=dev(dead))
+    slot_of, dead_list = ops.dead_compact(dev(dead), n_dead)
+    acts, slots = auxk_select_compact(x, W, b, dead_list, n_dead, k)
+    got_idx = dead_list[slots]
+    order_a, order_b = got_idx.argsort(-1), want_idx.argsort(-1)
+    assert torch.equal(got_idx.gather(-1, order_a), want_idx.gather(-1, order_b))
+    assert torch.equal(acts.gather(-1, order_a).view(torch.int16), want_acts.gather(-1, order_b).view(torch.int16))
