@@ -96,7 +96,9 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
 
     // group maxima per thread in use: about twice as many maxima as k, so that tau (the k-th
     // largest of them) sits near their median and not at their minimum
-    bool exact = k > 3 * TK_THREADS;
+    // short rows with a large k (the compact AuxK selection: k = 2048 of ~13 k): ~18 sweeps of a
+    // cache-resident row are cheaper than sorting thousands of candidates
+    bool exact = k > 3 * TK_THREADS || (k >= 256 && (int64_t)M <= 16ll * k);
     const int R = k <= TK_THREADS / 2 ? 1 : (k <= TK_THREADS ? 2 : TK_GROUPS);
     if (!exact) {
         const int T_ = (M + TK_TILE - 1) / TK_TILE;
