@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal with --gpus 1: run the data-parallel gradient exchange over a one-rank group")
     ap.add_argument("--no-overlap", action="store_true", help="gradient exchange on the compute stream (A/B)")
+    ap.add_argument("--optimizer", default="signsgd", choices=["signsgd", "signum", "adam", "muon"],
+                    help="signsgd (pinned to the reference's sign_sgd.py) is the headline; signum = the reference's "
+                         "default, schedule-free SignSGD (third-party package: parity unpinned)")
     args = ap.parse_args()
 
     if os.environ.get("SPHIP_HANG_DUMP"):      # debugging aid: dump all stacks if the run stalls
@@ -136,7 +139,7 @@ def main():
 
     w = WORKLOADS[args.workload]
     N, D, M, k = args.tokens, w["d_in"], w["num_latents"], w["k"]
-    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["layers.10"],
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer=args.optimizer, hookpoints=["layers.10"],
                       save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False,
                       overlap_exchange=not args.no_overlap)
     total = args.warmup + args.steps
@@ -202,7 +205,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16",
             "data": "synthetic",
-            "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": "signsgd",
+            "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": args.optimizer,
                        "params": "fp32", "parallelism": f"dp{world}", "mean_fvu": fvu},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
