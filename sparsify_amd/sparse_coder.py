@@ -180,7 +180,10 @@ class SparseCoder(nn.Module):
     # Same autocast wrapper as the reference (sparse_coder.py:204-209): the encoder linear
     # (and the skip matmul) run in bf16, everything else in fp32.
     @torch.autocast("cuda", dtype=torch.bfloat16, enabled=torch.cuda.is_available())
-    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None) -> ForwardOutput:
+    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None,
+                num_dead: int | None = None) -> ForwardOutput:
+        """num_dead (not in the reference): int(dead_mask.sum()) if the caller already holds it;
+        otherwise it is read here, which makes the host wait for the device mid-forward."""
         top_acts, top_indices, pre_acts = self.encode(x)
 
         if y is None:
@@ -195,7 +198,9 @@ class SparseCoder(nn.Module):
         total_variance = ops.total_variance(y2)                     # sparse_coder.py:228
         fvu, e = ResidualLoss.apply(sae_out, y, total_variance)      # :225, :253-254
 
-        if dead_mask is not None and (num_dead := int(dead_mask.sum())) > 0:
+        if dead_mask is not None and num_dead is None:
+            num_dead = int(dead_mask.sum())
+        if dead_mask is not None and num_dead > 0:
             k_aux = y.shape[-1] // 2                                  # :233
             scale = min(num_dead / k_aux, 1.0)
             k_aux = min(k_aux, num_dead)

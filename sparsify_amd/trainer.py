@@ -270,12 +270,17 @@ class Trainer:
             else:
                 raw.set_decoder_norm_to_unit_norm()
 
-        dead_mask = None
+        dead_mask = num_dead = None
         if cfg.auxk_alpha > 0:
-            dead_mask, _ = ops.dead_mask(self.num_tokens_since_fired[name], cfg.dead_feature_threshold)
+            dead_mask, n_dead = ops.dead_mask(self.num_tokens_since_fired[name], cfg.dead_feature_threshold)
+            # the AuxK branch needs the count on the host (sparse_coder.py:231, k_aux is a shape):
+            # read it here, before the forward is enqueued, where the GEMM covers the host's catching
+            # up -- inside the forward the same wait leaves the GPU idle while the backward is enqueued
+            num_dead = int(n_dead)
 
         self._install_grad_hooks()
-        out = raw(x=inputs, y=outputs, dead_mask=dead_mask)
+        out = (raw(x=inputs, y=outputs, dead_mask=dead_mask, num_dead=num_dead) if num_dead is not None and isinstance(raw, SparseCoder)
+               else raw(x=inputs, y=outputs, dead_mask=dead_mask))
 
         ops.mark_fired_(self.did_fire[name], out.latent_indices.reshape(-1))      # trainer.py:422
         self.maybe_all_reduce(self.did_fire[name], "max")
