@@ -34,6 +34,37 @@ class SignSGD(Optimizer):
         # ids of "renorm_rows" parameters whose rows were left unit-norm by the last step();
         # the trainer consumes an id instead of normalising that decoder again
         self.renormalised: set[int] = set()
+        self._early_hooks: list = []
+        self._early_done: dict[int, tuple] = {}
+        self.early_exchanges = 0                   # how often a hook started an exchange (tests)
+
+    # fraction of a decoder matrix's rows whose exchange starts as soon as its gradient exists
+    EARLY_FRACTION = 0.5
+
+    def enable_early_exchange(self, params) -> None:
+        """Overlapped data-parallel step only: start the exchange (and update) of the first
+        EARLY_FRACTION of the rows of `params` (decoder matrices) from a post-accumulate-grad
+        hook, i.e. inside the backward as soon as their gradient is complete, under the rest of
+        the backward. step() then exchanges the remaining rows after the encoder matrices. The
+        wire is busy earlier, the update is the same. Needs one backward per step()."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if any(p is q for q in params) and p.is_cuda and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._early_hooks.append(p.register_post_accumulate_grad_hook(
+                        lambda t, g=group: self._early_hook(t, g)))
+
+    def _early_hook(self, p, group) -> None:
+        if not (self.overlap and self.reduces(p)) or p.grad is None or not p.grad.is_contiguous():
+            return
+        w = parallel.world_size()
+        rows = int(p.shape[0] * self.EARLY_FRACTION) // w * w
+        if rows <= 0 or rows >= p.shape[0] or id(p) in self._early_done:
+            return
+        with torch.no_grad():
+            events = self._exchange_step(p, p.grad, group["lr"], group.get("project_rows", False),
+                                         group.get("renorm_rows", False), overlap=True, rows=(0, rows), finish=False)
+        self._early_done[id(p)] = (rows, events)
+        self.early_exchanges += 1
 
     def fuse_encoder_update(self, weights) -> None:
         """Optimizer-in-backward for encoder matrices (not in the reference): FusedEncoder's
@@ -95,9 +126,14 @@ class SignSGD(Optimizer):
         # overlapped exchanges, in the order the next forward needs the results: encoder
         # matrices (read by the GEMM that opens it) before decoder matrices (read after top-k)
         for item in sorted(deferred, key=lambda it: it[3]):
-            self._exchange_step(*item, overlap=True)
+            early = self._early_done.pop(id(item[0]), None)
+            if early is None:
+                self._exchange_step(*item, overlap=True)
+            else:                                  # the first rows went out during the backward
+                self._exchange_step(*item, overlap=True, rows=(early[0], item[0].shape[0]), prior=early[1])
 
-    def _exchange_step(self, p, g, lr, project: bool, renorm: bool, overlap: bool = False):
+    def _exchange_step(self, p, g, lr, project: bool, renorm: bool, overlap: bool = False, rows=None, prior=None,
+                       finish: bool = True):
         """One large matrix under data parallelism: see parallel.SignExchange."""
         w = p.data
         shadow = None if project else peek_bf16_shadow(p)
@@ -107,42 +143,56 @@ class SignSGD(Optimizer):
         else:
             def apply_fn(signs, lo, hi):
                 ops.apply_signs_(w[lo:hi], signs, lr, None if shadow is None else shadow[lo:hi])
-        self.run_exchange(p, g, project, apply_fn, overlap)
-        if project and renorm:
-            self.renormalised.add(id(p))
-        if shadow is not None:
-            register_bf16_shadow(p, shadow)
+        events = self.run_exchange(p, g, project, apply_fn, overlap, rows=rows, prior=prior, finish=finish)
+        if finish:
+            if project and renorm:
+                self.renormalised.add(id(p))
+            if shadow is not None:
+                register_bf16_shadow(p, shadow)
+        return events
 
-    def run_exchange(self, p, g, project: bool, apply_fn, overlap: bool) -> None:
+    def run_exchange(self, p, g, project: bool, apply_fn, overlap: bool, rows=None, prior=None, finish: bool = True):
         """Reduce-scatter the gradient, take the signs (decoder matrices: of the gradient
         projected on the complement of the parameter's rows), all-gather them and hand them to
         `apply_fn(signs, row_lo, row_hi)`; with `overlap` on the exchange stream, recording one
         event per finished row block (parallel.set_pending). Also used by the schedule-free
-        wrapper, whose apply_fn is its own step."""
+        wrapper, whose apply_fn is its own step. `rows` = (lo, hi) restricts the call to a row
+        range (early exchange); `prior` are the events of rows exchanged before; with finish =
+        False the events are returned instead of published (more rows follow)."""
         w = p.data
+        r0, r1 = (0, p.shape[0]) if rows is None else rows
         if project:
             def sign_fn(shard, lo, hi):
-                return ops.decoder_project_sign_i8(w[lo:hi], shard)
+                return ops.decoder_project_sign_i8(w[r0 + lo:r0 + hi], shard)
         else:
             def sign_fn(shard, lo, hi):
                 return ops.sign_i8(shard)
+
+        def apply_rows(signs, lo, hi):
+            apply_fn(signs, r0 + lo, r0 + hi)
+
+        g_rows = g if rows is None else g[r0:r1]
+        done: list = list(prior or [])
         if overlap:
             cur = torch.cuda.current_stream(p.device)
             side = parallel.exchange_stream(p.device)
-            parallel.wait_for(p)                   # an earlier update of p that nobody read
+            if not prior:
+                parallel.wait_for(p)               # an earlier update of p that nobody read
             side.wait_stream(cur)                  # the gradient (and p's last readers) are done
             g.record_stream(side)                  # zero_grad() must not recycle it under the exchange
-            blocks = 1 if project else parallel.SignExchange.row_blocks(p.shape[0], self.OVERLAP_BLOCKS, 256)
-            done: list = []
+            blocks = 1 if project else parallel.SignExchange.row_blocks(r1 - r0, self.OVERLAP_BLOCKS, 256)
 
             def on_block(lo, hi):
                 ev = torch.cuda.Event()
                 ev.record(side)
-                done.append((lo, hi, ev))
+                done.append((r0 + lo, r0 + hi, ev))
 
             with torch.cuda.stream(side):
-                parallel.SignExchange.step(g, sign_fn, apply_fn, blocks=blocks, on_block=on_block)
-            parallel.set_pending(p, done)
+                parallel.SignExchange.step(g_rows, sign_fn, apply_rows, blocks=blocks, on_block=on_block)
+            if finish:
+                parallel.set_pending(p, done)
         else:
-            parallel.SignExchange.step(g, sign_fn, apply_fn)
-        torch.autograd.graph.increment_version(p)
+            parallel.SignExchange.step(g_rows, sign_fn, apply_rows)
+        if finish:
+            torch.autograd.graph.increment_version(p)
+        return done

@@ -171,6 +171,10 @@ class Trainer:
                 else:
                     opt = SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange)
                     self.optimizers = [opt]
+                    if opt.overlap and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and cfg.loss_fn == "fvu":
+                        # the decoder matrices' gradients are complete before the encoder backward
+                        # runs: their exchange starts there (first half of the rows)
+                        opt.enable_early_exchange([sae.W_dec for sae in self.saes.values() if sae.W_dec is not None])
                     one_rank = not (dist.is_initialized() and dist.get_world_size() > 1)
                     if (cfg.fuse_encoder_update and one_rank and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
                             and cfg.loss_fn == "fvu" and self.device.type == "cuda"):

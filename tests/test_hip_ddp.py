@@ -115,6 +115,7 @@ def _rccl_one_rank(port, ret):
             out[mode] = {n: p.detach().cpu() for n, p in tr.saes["h0"].named_parameters()}
             out[mode]["fvu"] = tr.last_logged["fvu/h0"]
             out[mode]["block_launches"] = len(ops.timer.events.get("sphip_encoder_preacts_block", []))
+            out[mode]["early"] = getattr(tr.optimizers[0], "early_exchanges", 0)
         ret[0] = out
     finally:
         dist.destroy_process_group()
@@ -139,8 +140,11 @@ def test_overlapped_exchange_over_rccl_one_rank(device):
         plain = out[(opt, "allreduce")]
         for how in MODES[1:]:
             for name, ref in plain.items():
-                if name not in ("fvu", "block_launches"):
+                if name not in ("fvu", "block_launches", "early"):
                     assert torch.equal(ref, out[(opt, how)][name]), f"{opt}/{how}: {name} differs from the plain step"
             assert out[(opt, how)]["fvu"] == plain["fvu"]
         assert plain["block_launches"] == 0 and out[(opt, "exchange")]["block_launches"] == 0
         assert out[(opt, "overlap")]["block_launches"] == 5 * 8    # steps 2..6, SignSGD.OVERLAP_BLOCKS each
+        # plain SignSGD: the decoder matrix's first rows leave from a hook inside every backward
+        assert out[(opt, "overlap")]["early"] == (6 if opt == "signsgd" else 0)
+        assert out[(opt, "exchange")]["early"] == 0
