@@ -33,6 +33,8 @@ WORKLOADS = {
     "llama3-8b-layer d_in=4096 M=131072 k=192": dict(d_in=4096, num_latents=131072, k=192),
     # BASELINE.json configs[0] (CPU-runnable reference case), for quick checks
     "gpt2-small d_in=768 M=24576 k=32": dict(d_in=768, num_latents=24576, k=32),
+    # BASELINE.json configs[4]: MLP transcoder, 262144 latents, for --mode shard (latents split over the ranks)
+    "llama3-8b-transcoder d_in=4096 M=262144 k=192": dict(d_in=4096, num_latents=262144, k=192, transcode=True),
 }
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s
@@ -106,6 +108,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal with --gpus 1: run the data-parallel gradient exchange over a one-rank group")
     ap.add_argument("--no-overlap", action="store_true", help="gradient exchange on the compute stream (A/B)")
+    ap.add_argument("--mode", default="ddp", choices=["ddp", "shard"],
+                    help="ddp: replicas, tokens split over the ranks (weak scaling, the headline); shard: the latents of "
+                         "one dictionary split over the ranks, every rank sees the same tokens (strong scaling)")
     ap.add_argument("--optimizer", default="signsgd", choices=["signsgd", "signum", "adam", "muon"],
                     help="signsgd (pinned to the reference's sign_sgd.py) is the headline; signum = the reference's "
                          "default, schedule-free SignSGD (third-party package: parity unpinned)")
@@ -139,12 +144,15 @@ def main():
 
     w = WORKLOADS[args.workload]
     N, D, M, k = args.tokens, w["d_in"], w["num_latents"], w["k"]
-    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer=args.optimizer, hookpoints=["layers.10"],
+    shard = args.mode == "shard"
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, transcode=bool(w.get("transcode"))), shard_latents=shard,
+                      optimizer=args.optimizer, hookpoints=["layers.10"],
                       save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False,
                       overlap_exchange=not args.no_overlap)
     total = args.warmup + args.steps
     src = SyntheticActivations(["layers.10"], D, N, total, device=device,
-                               dtype=torch.float32 if args.fp32 else torch.bfloat16, rank=rank)
+                               dtype=torch.float32 if args.fp32 else torch.bfloat16, rank=0 if shard else rank,
+                               transcode=bool(w.get("transcode")))
     trainer = Trainer(cfg, src, device=device)
     sae = trainer.saes["layers.10"]
     if args.fp32:
@@ -185,7 +193,7 @@ def main():
         gemm_ms = sum(kern[n]["total_ms"] for n in ("sphip_encoder_preacts", "sphip_encoder_preacts_block")
                       if n in kern) / args.steps
         gemm = {"mean_ms": gemm_ms}
-        flops = 2.0 * N * D * M                                   # algorithmic FLOP per step
+        flops = 2.0 * N * D * M / (world if shard else 1)        # algorithmic FLOP per step and rank
         tflops = flops / (gemm["mean_ms"] * 1e-3) / 1e12
         dec = kern["sphip_gather_rows_weighted"]
         wg = kern["sphip_segmented_weight_grad"]
@@ -194,19 +202,19 @@ def main():
         traffic, mfma_util = measured_traffic("sphip::encoder_gemm256_kernel<true") if headline else (None, None)
         out = {
             "metric": "SAE train tokens/sec at d=4096, M=131072, k=192 (1-8 GPUs); MFMA util %",
-            "value": N * world * args.steps / elapsed,
+            "value": N * (1 if shard else world) * args.steps / elapsed,
             "unit": "tokens/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16",
             "data": "synthetic",
             "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": args.optimizer,
-                       "params": "fp32", "parallelism": f"dp{world}", "mean_fvu": fvu},
+                       "params": "fp32", "parallelism": f"latent-shard{world}" if shard else f"dp{world}", "mean_fvu": fvu},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) from the committed "
@@ -214,7 +222,8 @@ def main():
                          "mfma_util_pct_profiled": None if mfma_util is None else 100.0 * mfma_util,
                          "kernel": "encoder_gemm256_kernel (sphip_encoder_preacts)", "ms": gemm["mean_ms"]},
             "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in kern.items()},
-            "hbm_kernels": {
+            # per-rank partial work in shard mode: the one-GPU byte counts do not apply
+            "hbm_kernels": None if shard else {
                 "decode_gather_GBs": gather_bytes / (dec["total_ms"] / dec["calls"] * 1e-3) / 1e9,
                 "segmented_wgrad_GBs": 2 * N * k * D * 4 / (wg["total_ms"] / args.steps * 1e-3) / 1e9,
                 # M*2 B read per token (the kernel itself reads ~1/4 of that)

@@ -74,6 +74,11 @@ class TrainConfig(_Serializable):
     """(not in the reference) run that exchange and the updates it feeds on a second stream, under
     the next forward: the encoder GEMM follows the arriving row blocks (same update, same
     results; parallel.wait_for_updates() before reading parameters outside the Trainer)."""
+    shard_latents: bool = False
+    """(not in the reference; BASELINE.json configs[4]) split every coder's latents over the ranks
+    (sharded.ShardedSparseCoder): all ranks see the same tokens, the only exchanges are the top-k
+    candidates and the partial reconstructions, gradients and optimizer state stay shard-local.
+    Plain top-k FVU step only (no AuxK, multi-top-k or end-to-end loss)."""
     fuse_encoder_update: bool = True
     """(not in the reference) "signsgd" on one rank without gradient accumulation: apply the step of
     `encoder.weight` inside its gradient kernel (same update; the (M, D) gradient is never
@@ -97,5 +102,9 @@ class TrainConfig(_Serializable):
                 "Distributing modules across ranks is not compatible with the "
                 "cross-entropy or KL divergence losses."
             )
+        if self.shard_latents and (self.distribute_modules or self.loss_fn != "fvu" or self.auxk_alpha > 0
+                                   or self.sae.multi_topk or self.sae.activation != "topk"):
+            raise ValueError("`shard_latents` implements the plain top-k FVU step: no distribute_modules, "
+                             "ce / kl loss, AuxK, multi-top-k or groupmax")
         if not self.init_seeds:
             raise ValueError("Must specify at least one random seed.")

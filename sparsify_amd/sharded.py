@@ -129,6 +129,31 @@ class ShardedSparseCoder(nn.Module):
     def dtype(self):
         return self.encoder.weight.dtype
 
+    @property
+    def device(self):
+        return self.encoder.weight.device
+
+    def save_to_disk(self, path):
+        """Collective: the shards are gathered and rank 0 writes the reference's unsharded
+        checkpoint (cfg.json + sae.safetensors, sparse_coder.py:167-179), which
+        SparseCoder.load_from_disk -- and the reference -- load as an ordinary coder."""
+        import json
+        from pathlib import Path
+
+        from safetensors.torch import save_file
+        tensors = {
+            "W_dec": parallel.all_gather_rows(self.W_dec.data),
+            "b_dec": self.b_dec.data,
+            "encoder.bias": parallel.all_gather_rows(self.encoder.bias.data),
+            "encoder.weight": parallel.all_gather_rows(self.encoder.weight.data),
+        }
+        if parallel.rank() == 0:
+            path = Path(path)
+            path.mkdir(parents=True, exist_ok=True)
+            save_file({k: v.detach().contiguous().cpu() for k, v in tensors.items()}, str(path / "sae.safetensors"))
+            with open(path / "cfg.json", "w") as f:
+                json.dump({**self.cfg.to_dict(), "d_in": self.d_in}, f)
+
     @torch.autocast("cuda", dtype=torch.bfloat16, enabled=torch.cuda.is_available())
     def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None) -> ForwardOutput:
         if dead_mask is not None or self.cfg.multi_topk or self.cfg.activation != "topk":

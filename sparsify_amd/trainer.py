@@ -95,7 +95,11 @@ class Trainer:
                 for seed in cfg.init_seeds:
                     torch.manual_seed(seed)
                     name = f"{hook}/seed{seed}" if len(cfg.init_seeds) > 1 else hook
-                    self.saes[name] = SparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
+                    if cfg.shard_latents:
+                        from .sharded import ShardedSparseCoder
+                        self.saes[name] = ShardedSparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
+                    else:
+                        self.saes[name] = SparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
 
         # the source yields one micro-batch per item (the reference counts sequences:
         # len(dataset) // batch_size, trainer.py:90)
@@ -143,7 +147,7 @@ class Trainer:
                 muon_params = [p for p in params if p.ndim >= 2]
                 rest = [p for p in params if p.ndim < 2]
                 self.optimizers = [
-                    Muon(muon_params, lr=cfg.lr or 2e-3, ddp=not cfg.distribute_modules),
+                    Muon(muon_params, lr=cfg.lr or 2e-3, ddp=not (cfg.distribute_modules or cfg.shard_latents)),
                     torch.optim.Adam(rest, lr=cfg.lr or 2e-3),
                 ]
                 self.lr_schedulers = [
@@ -164,12 +168,14 @@ class Trainer:
                         pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
                 if cfg.optimizer == "signum":
-                    opt = ScheduleFreeWrapper(SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange),
+                    opt = ScheduleFreeWrapper(SignSGD(pgs, exchange_signs=cfg.exchange_signs and not cfg.shard_latents,
+                                                      overlap=cfg.overlap_exchange),
                                               momentum=0.95)
                     opt.train()
                     self.optimizers = [opt]
                 else:
-                    opt = SignSGD(pgs, exchange_signs=cfg.exchange_signs, overlap=cfg.overlap_exchange)
+                    exchange = cfg.exchange_signs and not cfg.shard_latents      # shard gradients are local
+                    opt = SignSGD(pgs, exchange_signs=exchange, overlap=cfg.overlap_exchange)
                     self.optimizers = [opt]
                     if opt.overlap and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and cfg.loss_fn == "fvu":
                         # the decoder matrices' gradients are complete before the encoder backward
@@ -194,12 +200,14 @@ class Trainer:
     # ------------------------------------------------------------------ distributed helpers
     @property
     def ddp(self) -> bool:
-        return dist.is_initialized() and dist.get_world_size() > 1 and not self.cfg.distribute_modules
+        # latent shards hold different rows of one dictionary: nothing to broadcast or average
+        return (dist.is_initialized() and dist.get_world_size() > 1 and not self.cfg.distribute_modules
+                and not self.cfg.shard_latents)
 
     def maybe_all_reduce(self, x: Tensor, op: str = "mean") -> Tensor:
         """trainer.py:614-628"""
-        if not dist.is_initialized() or self.cfg.distribute_modules:
-            return x
+        if not dist.is_initialized() or self.cfg.distribute_modules or self.cfg.shard_latents:
+            return x        # (latent shards: every rank sees the same tokens, the values already agree)
         return parallel.all_reduce_(x, op)
 
     def distribute_modules(self):
@@ -311,6 +319,9 @@ class Trainer:
         did_step = False
         if substep == 0:
             self._finish_grad_reduce()
+            if cfg.shard_latents:
+                for sae in self.saes.values():
+                    sae.reduce_shared_grads()          # b_dec: the one parameter the shards share
             if cfg.sae.normalize_decoder and not cfg.sae.transcode and not self._fused_projection:
                 for sae in self.saes.values():
                     sae.remove_gradient_parallel_to_decoder_directions()
@@ -421,7 +432,7 @@ class Trainer:
     def save(self):
         path = f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}'
         rank_zero = not dist.is_initialized() or dist.get_rank() == 0
-        if self.cfg.save_dir and (rank_zero or self.cfg.distribute_modules):
+        if self.cfg.save_dir and (rank_zero or self.cfg.distribute_modules or self.cfg.shard_latents):
             Path(path).mkdir(parents=True, exist_ok=True)
             self._checkpoint(self.saes, path, rank_zero)
         if dist.is_initialized():

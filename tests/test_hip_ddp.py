@@ -148,3 +148,71 @@ def test_overlapped_exchange_over_rccl_one_rank(device):
         # plain SignSGD: the decoder matrix's first rows leave from a hook inside every backward
         assert out[(opt, "overlap")]["early"] == (6 if opt == "signsgd" else 0)
         assert out[(opt, "exchange")]["early"] == 0
+
+
+def _shard_worker(rank, world, port, ret, save_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _train_small(shard=True, save_dir=save_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+def _train_small(shard, save_dir=""):
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.trainer import SyntheticActivations, Trainer
+    D, M, k, N, steps = 128, 2048, 16, 512, 5
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"], save_dir=save_dir,
+                      run_name="run", save_every=10**9, wandb_log_frequency=1, shard_latents=shard)
+    src = SyntheticActivations(["h0"], D, N, steps, device="cuda", rank=0)      # every rank sees the same tokens
+    torch.manual_seed(0)
+    tr = Trainer(cfg, src, device="cuda")
+    fvus = []
+    for s in range(steps):
+        tr.train_micro_batch(src.batch(s))
+        fvus.append(tr.last_logged["fvu/h0"])
+    if save_dir:
+        tr.save()
+    torch.cuda.synchronize()
+    sae = tr.saes["h0"]
+    return {"fvu": fvus, "rows": tuple(sae.encoder.weight.shape), "W_dec": sae.W_dec.detach().cpu(),
+            "W_enc": sae.encoder.weight.detach().cpu(), "b_dec": sae.b_dec.detach().cpu()}
+
+
+def test_latent_sharded_trainer_matches_unsharded(device, tmp_path):
+    """TrainConfig.shard_latents with two ranks on one GPU: each rank trains half of the latents of
+    one dictionary on the same tokens. The FVU curve and the parameters follow the unsharded
+    Trainer (the reconstruction is a sum of two partial sums, so a gradient at the rounding level
+    may take the other sign), and the checkpoint rank 0 writes from the gathered shards is an
+    ordinary unsharded one."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, ret, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=90)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank did not finish (collective mismatch?)")
+        assert p.exitcode == 0
+    ref = _train_small(shard=False)
+    r0, r1 = ret[0], ret[1]
+    assert r0["rows"] == (1024, 128) and r1["rows"] == (1024, 128)
+    assert r0["fvu"] == r1["fvu"]                                   # replicated loss, identical on the ranks
+    for a, b in zip(r0["fvu"], ref["fvu"]):
+        assert abs(a - b) <= 2e-3 * b, (r0["fvu"], ref["fvu"])
+    assert ref["fvu"][-1] < 1.0
+    assert torch.equal(r0["b_dec"], r1["b_dec"])                    # the one shared parameter stays replicated
+    for name in ("W_dec", "W_enc"):
+        whole = torch.cat([r0[name], r1[name]])
+        assert (whole != ref[name]).float().mean() < 0.01, name
+    from sparsify_amd import SparseCoder
+    back = SparseCoder.load_from_disk(tmp_path / "run" / "h0")
+    assert back.num_latents == 2048 and back.d_in == 128
+    assert torch.equal(back.W_dec.detach(), torch.cat([r0["W_dec"], r1["W_dec"]]))
+    assert torch.equal(back.encoder.weight.detach(), torch.cat([r0["W_enc"], r1["W_enc"]]))
