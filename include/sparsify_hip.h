@@ -136,7 +136,8 @@ int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_
  * Sums run in segment order, so results are bitwise reproducible.
  * workspace (sphip_weight_grad_workspace_bytes): the segment-ordered (entry, coeff) list plus
  *   either a slice-major copy of rows (no dcoeff) or the per-column-slice partial dots of
- *   dcoeff (D/256 floats per entry), whichever is larger. */
+ *   dcoeff (D/256 floats per entry), whichever is larger, plus the list of latents with very
+ *   long segments (dense latents), which a second kernel takes over from the L2-sliced one. */
 size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
 int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                 int coeff_dtype, const void* rows, int rows_dtype, const float* W,

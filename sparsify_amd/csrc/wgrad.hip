@@ -171,9 +171,13 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                                                                const float* __restrict__ row_shift, FastDiv kdiv,
                                                                int64_t N, int M, int D, int blocks_per_slice,
                                                                int num_slices, float lr = 0.f,
-                                                               bf16_t* __restrict__ shadow = nullptr) {
+                                                               bf16_t* __restrict__ shadow = nullptr,
+                                                               const int* __restrict__ skew = nullptr, int skew_T = 0) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
+    // a workgroup holds 32 latents for as long as its longest segment lasts: with `skew` set,
+    // segments longer than skew_T are left to the wave-per-latent wide kernel launched next
+    // to this one (seg_long_list_kernel lists them)
     // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
     const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const unsigned slice = xcd + 8 * (local / (unsigned)blocks_per_slice);
@@ -183,10 +187,12 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     const int grp = lane >> 3, sub = lane & 7;
     const int j = (int)lblock * 32 + (threadIdx.x >> 6) * 8 + grp;
     const int col = (int)slice * SLICE_COLS + sub * C;
-    const bool live = (j < M) && (col < D);
+    bool live = (j < M) && (col < D);
 
     int beg = 0, end = 0;
     if (j < M) { beg = seg_begin[j]; end = seg_begin[j + 1]; }
+    const bool mine = skew == nullptr || end - beg <= skew_T;
+    if (!mine) { beg = end = 0; live = false; }
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             }
         }
     }
-    if (gbias != nullptr && slice == 0 && sub == 0 && j < M) gbias[j] = bsum;
+    if (gbias != nullptr && slice == 0 && sub == 0 && j < M && mine) gbias[j] = bsum;
 }
 
 // gbias[j] = sum of the coefficients of latent j's segment, in segment order (the same chain as
@@ -297,18 +303,46 @@ __global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __re
 // and lanes 0, 8, .., 56 store 8 consecutive floats of the slab[slice][position] array;
 // seg_dcoeff_kernel then sums the slices in a fixed order. Entry metadata is wave-uniform
 // (scalar loads). gW is summed in segment order: bitwise the same as the full-row kernel.
-template <typename RT, bool DOT>
+template <typename RT, bool DOT, bool FUSE>
+__device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, const int* __restrict__ seg_begin,
+                                            const RT* __restrict__ rows, const float* __restrict__ W,
+                                            float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
+                                            const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
+                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow);
+
+template <typename RT, bool DOT, bool FUSE = false, bool LIST = false>
 __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __restrict__ packed,
                                                              const int* __restrict__ seg_begin,
                                                              const RT* __restrict__ rows,
                                                              const float* __restrict__ W, float* __restrict__ gW,
                                                              float* __restrict__ gbias, float* __restrict__ slab,
                                                              const float* __restrict__ row_shift, FastDiv kdiv,
-                                                             int64_t E, int M, int D) {
+                                                             int64_t E, int M, int D,
+                                                             const int* __restrict__ skew = nullptr, int skew_T = 0,
+                                                             float lr = 0.f, bf16_t* __restrict__ shadow = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (j >= M) return;
+    const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = blockIdx.y;
+    if (LIST) {
+        // launched next to the L2-sliced kernel with a small fixed grid: the waves walk the list
+        // of long latents (skew[0] = their number, skew[1..] = the latents; usually empty)
+        const int n_long = skew[0];
+        for (int i = wv; i < n_long; i += (int)gridDim.x * 4)
+            wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D,
+                                       __builtin_amdgcn_readfirstlane(skew[1 + i]), slice, lane, lr, shadow);
+        return;
+    }
+    if (wv >= M) return;
+    wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D, wv, slice, lane, lr,
+                               shadow);
+}
+
+template <typename RT, bool DOT, bool FUSE>
+__device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, const int* __restrict__ seg_begin,
+                                            const RT* __restrict__ rows, const float* __restrict__ W,
+                                            float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
+                                            const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
+                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow) {
     const int col = slice * 256 + lane * 4;
     const int beg = seg_begin[j], end = seg_begin[j + 1];
     const float4 w = DOT ? *reinterpret_cast<const float4*>(W + (int64_t)j * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -376,8 +410,32 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
         acc.z = fmaf(-bsum, sh.z, acc.z);
         acc.w = fmaf(-bsum, sh.w, acc.w);
     }
-    *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
+    if (FUSE) {       // gW is the parameter: SignSGD step in place (see seg_wgrad_sliced_kernel)
+        float4 p4 = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col);
+        p4.x -= lr * (float)((acc.x > 0.f) - (acc.x < 0.f));
+        p4.y -= lr * (float)((acc.y > 0.f) - (acc.y < 0.f));
+        p4.z -= lr * (float)((acc.z > 0.f) - (acc.z < 0.f));
+        p4.w -= lr * (float)((acc.w > 0.f) - (acc.w < 0.f));
+        *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = p4;
+        if (shadow != nullptr) {
+            const unsigned lo = (unsigned)f32_to_bf16(p4.x) | ((unsigned)f32_to_bf16(p4.y) << 16);
+            const unsigned hi = (unsigned)f32_to_bf16(p4.z) | ((unsigned)f32_to_bf16(p4.w) << 16);
+            *reinterpret_cast<uint2*>(shadow + (int64_t)j * D + col) = make_uint2(lo, hi);
+        }
+    } else {
+        *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
+    }
     if (gbias != nullptr && slice == 0 && lane == 0) gbias[j] = bsum;
+}
+
+// latents whose segment is longer than T: out[0] = their number (zeroed before the launch),
+// out[1..] = the latents, in arrival order (the order only decides which wave takes which)
+__global__ __launch_bounds__(256) void seg_long_list_kernel(const int* __restrict__ seg_begin, int M, int T, int cap,
+                                                            int* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M || seg_begin[j + 1] - seg_begin[j] <= T) return;
+    const int pos = atomicAdd(out, 1);
+    if (pos < cap) out[1 + pos] = j;
 }
 
 // dcoeff[entry at position p] = sum over slices of slab[slice][p], slices in ascending order
@@ -392,10 +450,15 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
     dcoeff[packed[p].x] = t;
 }
 
+// segments longer than this go from the L2-sliced kernel to the wide kernel, whose waves (a small
+// fixed grid of LONG_GRID workgroups per column slice) walk the list of such latents
+constexpr int SKEW_T = 512;
+constexpr unsigned LONG_GRID = 256;
+
 template <typename RT, bool FUSE = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
-                          float lr = 0.f, bf16_t* shadow = nullptr) {
+                          float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -411,7 +474,7 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     if (nblocks >= (1ll << 31)) return false;
     hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                        (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                       shadow);
+                       shadow, skew, SKEW_T);
     return true;
 }
 
@@ -440,11 +503,21 @@ static size_t slab_bytes(int64_t N, int64_t k, int64_t D) {
     return wide_eligible(D) ? (size_t)(D / 256) * (size_t)N * (size_t)k * sizeof(float) : 0;
 }
 
+extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
+static size_t long_list_bytes(int64_t N, int64_t k) {
+    return (((size_t)(N * k / sphip::SKEW_T + 2) * sizeof(int)) + 255) & ~(size_t)255;
+}
+// the list of long latents sits at the end of the workspace
+static int* skew_word(void* workspace, int64_t N, int64_t k, int64_t D) {
+    return (int*)((char*)workspace + sphip_weight_grad_workspace_bytes(N, k, D) - long_list_bytes(N, k));
+}
+
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
     if (N <= 0 || k <= 0 || D <= 0) return 0;
     // packed entry list + max(slice-major copy of `rows` (no dcoeff), per-slice dot slab (dcoeff))
     const size_t a = rows_sm_bytes(N, D), b = slab_bytes(N, k, D);
-    return packed_bytes(N, k) + (a > b ? a : b);
+    // + the list of long latents (at most N k / SKEW_T of them, preceded by their count)
+    return packed_bytes(N, k) + (((a > b ? a : b) + 255) & ~(size_t)255) + long_list_bytes(N, k);
 }
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
@@ -503,10 +576,25 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
         return SPHIP_OK;
     }
     if (!dot && !(force && (force[0] == 'f' || force[0] == 'w'))) {
+        // the L2-sliced kernel, and next to it the wide kernel: a device-side word (the longest
+        // segment) decides which of the two launches does the work, without a host round trip
+        int* skew = (wide_eligible(D) && big && !force) ? skew_word(workspace, N, k, D) : nullptr;
+        if (skew != nullptr) {
+            SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
+            hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
+        }
         const bool done = rows_dtype == SPHIP_F32
-                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s)
-                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s);
+                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew)
+                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew);
         if (done) {
+            if (skew != nullptr) {
+                const FastDiv kd = make_fastdiv((unsigned)k);
+                dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
+                if (rows_dtype == SPHIP_F32)
+                    hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, false, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T);
+                else
+                    hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, false, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T);
+            }
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
         }
@@ -566,10 +654,24 @@ extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const i
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
     else
         hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
+    const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
+    int* skew = (wide_eligible(D) && big) ? skew_word(workspace, N, k, D) : nullptr;
+    if (skew != nullptr) {
+        SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad_signsgd: memset failed");
+        hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
+    }
     const bool done = rows_dtype == SPHIP_F32
-                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow)
-                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow);
+                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew)
+                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew);
     SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
+    if (skew != nullptr) {
+        const FastDiv kd = make_fastdiv((unsigned)k);
+        dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
+        if (rows_dtype == SPHIP_F32)
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, true, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow);
+        else
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, true, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow);
+    }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad_signsgd");
     return SPHIP_OK;
 }

@@ -85,7 +85,10 @@ def _workspace(device: torch.device, nbytes: int, tag: str) -> Tensor:
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        # whole 2 MiB units: with an odd size the caching allocator placed the 290 MB weight-gradient
+        # workspace such that the kernels streaming through it ran 8 % slower (measured, same code)
+        nbytes = -(-max(nbytes, 1 << 16) // (2 << 20)) * (2 << 20) if nbytes > (1 << 20) else max(nbytes, 1 << 16)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 

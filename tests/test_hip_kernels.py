@@ -570,3 +570,37 @@ def test_auxk_compact_selection_equals_masked_topk(device, N, D, M, n_dead, k):
     order_a, order_b = got_idx.argsort(-1), want_idx.argsort(-1)
     assert torch.equal(got_idx.gather(-1, order_a), want_idx.gather(-1, order_b))
     assert torch.equal(acts.gather(-1, order_a).view(torch.int16), want_acts.gather(-1, order_b).view(torch.int16))
+
+
+@pytest.mark.parametrize("skewed", [False, True])
+@pytest.mark.parametrize("rdtype", [torch.bfloat16, torch.float32])
+def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, skewed, rdtype):
+    """Without a dot part the L2-sliced kernel leaves latents with long segments (dense latents) to
+    the wave-per-latent wide kernel, launched next to it over a device-side list of them. Either
+    way the gradient equals the full-row kernel's bit for bit, and the fused SignSGD form
+    (sphip_segmented_weight_grad_signsgd) equals gradient + separate step."""
+    from sparsify_amd import ops
+    torch.manual_seed(5)
+    N, D, M, k, lr = 4096, 1024, 4096, 32, 3e-3          # N * D * 2 B = 8 MiB: the training-size dispatch
+    idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
+    if skewed:
+        idx[:, :3] = torch.tensor([7, 1000, 4095])      # three latents fire on every token: segments of 4096
+    idx, coeff = dev(idx), dev(torch.randn(N, k).to(torch.bfloat16))
+    rows = dev(torch.randn(N, D).to(rdtype))
+    shift = dev(torch.randn(D))
+    seg = ops.build_latent_segments(idx, M)
+    longest = int((seg.seg_begin[1:] - seg.seg_begin[:-1]).max())
+    assert longest >= N if skewed else longest < 128           # 512 is where the wide kernel takes over
+    gW, gb, _ = ops.segmented_weight_grad(seg, coeff, rows, want_bias=True, row_shift=shift)
+    monkeypatch.setenv("SPHIP_WGRAD", "full")
+    gW_full, gb_full, _ = ops.segmented_weight_grad(seg, coeff, rows, want_bias=True, row_shift=shift)
+    monkeypatch.delenv("SPHIP_WGRAD")
+    assert torch.equal(gW, gW_full) and torch.equal(gb, gb_full)
+    # fused with the optimizer step
+    p0 = dev(torch.randn(M, D))
+    sep, fused = p0.clone(), p0.clone()
+    sh_sep, sh_fused = torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    ops.signsgd_step_(sep, gW, lr, sh_sep)
+    ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused, lr, sh_fused, row_shift=shift)
+    assert torch.equal(sep, fused) and torch.equal(sh_sep.view(torch.int16), sh_fused.view(torch.int16))
+    assert torch.equal(ops.segment_coeff_sums(seg, coeff), gb)
