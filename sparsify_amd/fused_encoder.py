@@ -118,6 +118,19 @@ class FusedEncoder(torch.autograd.Function):
         lead = input.shape[:-1]
         x2 = input.reshape(-1, input.shape[-1]).contiguous()
         low = _autocast_bf16() or (weight.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16)
+        ctx.empty = x2.shape[0] == 0
+        if ctx.empty:
+            ops._req(x2, "input")
+            # no rows: nothing to launch (torch's linear / topk return empty tensors here too)
+            odt = torch.bfloat16 if low else torch.float32
+            ctx.save_for_backward(x2, weight, bias, None, b_dec, None)
+            ctx.k, ctx.lead, ctx.in_shape = k, lead, input.shape
+            values = torch.empty(*lead, k, dtype=odt, device=x2.device)
+            indices = torch.empty(*lead, k, dtype=torch.int64, device=x2.device)
+            pre = torch.empty(*lead, weight.shape[0], dtype=odt, device=x2.device)
+            ctx.mark_non_differentiable(indices, pre)
+            ctx.set_materialize_grads(False)
+            return values, indices, pre
 
         shift = None
         if b_dec is not None and low and x2.dtype == torch.bfloat16:
@@ -181,6 +194,12 @@ class FusedEncoder(torch.autograd.Function):
         grad_input = grad_weight = grad_bias = grad_bdec = None
         if grad_values is None:
             return None, None, None, None, None, None
+        if ctx.empty:
+            need = ctx.needs_input_grad
+            return (torch.zeros(ctx.in_shape, dtype=torch.float32, device=weight.device) if need[0] else None,
+                    torch.zeros_like(weight) if need[1] else None,
+                    torch.zeros_like(bias) if bias is not None and need[2] else None, None, None,
+                    torch.zeros_like(b_dec) if b_dec is not None and need[5] else None)
         M = weight.shape[0]
         gv = grad_values.reshape(-1, ctx.k).contiguous()
         if weight.dtype != torch.float32:

@@ -17,6 +17,13 @@ class SparseDecode(torch.autograd.Function):
         ops.forget_segments(indices)
         parallel.wait_for(weight)                  # an overlapped optimizer update (sign_sgd.py)
         w = weight.detach()
+        ctx.empty = indices.shape[0] == 0
+        if ctx.empty:                              # no rows: nothing to launch
+            ops._req(indices, "indices", torch.int64, 2)
+            ctx.save_for_backward(indices, weight, per_sample_weights)
+            ctx.has_bias = bias is not None
+            ctx.set_materialize_grads(False)
+            return torch.empty(0, w.shape[1], dtype=torch.float32, device=w.device)
         out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
                                        None if bias is None else bias.detach())
         ctx.save_for_backward(indices, weight, per_sample_weights)
@@ -29,6 +36,11 @@ class SparseDecode(torch.autograd.Function):
         indices, weight, psw = ctx.saved_tensors
         if gradient is None:
             return None, None, None, None
+        if ctx.empty:
+            need = ctx.needs_input_grad
+            return (None, torch.zeros_like(weight) if need[1] else None, torch.zeros_like(psw) if need[2] else None,
+                    torch.zeros(weight.shape[1], dtype=torch.float32, device=weight.device)
+                    if ctx.has_bias and need[3] else None)
         g = gradient.contiguous()
         if g.dtype != torch.float32:
             g = g.float()

@@ -334,3 +334,25 @@ def test_fvu_after_1k_steps_within_1pct(device, mode):
     assert want[-100:].mean() < 0.6 * want[0], "the run must actually train"
     rel = abs(got[-100:].mean() - want[-100:].mean()) / want[-100:].mean()
     assert rel <= 0.01, f"FVU after 1k steps differs by {rel:.4%}"
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_empty_batch_like_torch(device, autocast):
+    """No rows (every token of a batch masked out): the reference's torch ops return empty
+    tensors and zero gradients (F.linear / topk / embedding_bag on (0, D)); so does the seam here."""
+    from sparsify_amd import fused_encoder
+    from sparsify_amd.utils import decoder_impl
+    D, M, k = 64, 512, 8
+    x = torch.empty(0, D, device="cuda", requires_grad=True)
+    W = torch.randn(M, D, device="cuda", requires_grad=True)
+    b = torch.zeros(M, device="cuda", requires_grad=True)
+    Wd = torch.randn(M, D, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        vals, idx, pre = fused_encoder(x, W, b, k, "topk")
+        out = decoder_impl(idx, vals.float(), Wd.mT)
+    assert vals.shape == (0, k) and idx.shape == (0, k) and idx.dtype == torch.int64 and pre.shape == (0, M)
+    assert vals.dtype == (torch.bfloat16 if autocast else torch.float32)
+    assert out.shape == (0, D) and out.dtype == torch.float32
+    out.sum().backward()
+    for t in (x, W, b, Wd):
+        assert t.grad is not None and t.grad.shape == t.shape and not t.grad.any()
