@@ -21,14 +21,21 @@
 //              of the k-th largest key over the whole row, then an index-ordered emission
 //              (block scans) that takes ties in ascending index order.
 // Both paths choose the same SET: all keys above the k-th key plus the lowest-index ties.
+// The kernel is instantiated for 1024 threads per row (any shape) and, for the tile path with
+// k <= 256, for 256 threads per row: a row's selection is a chain of ~80 workgroup barriers
+// (16 bisection steps, ~45 sort stages), so it is latency-bound, and four-wave workgroups pass a
+// barrier faster and put four times as many rows in flight per CU (8 KiB candidate list
+// instead of 64 KiB).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sphip {
 
-constexpr int TK_THREADS = 1024;
-constexpr int TK_WAVES = TK_THREADS / 64;
-constexpr int TK_CAP = 8192;   // candidate capacity (8 B each -> 64 KB LDS)
-constexpr int TK_GROUPS = 4;   // maxima kept per thread: the fast path covers k <= 4 * 1024
+constexpr int TK_THREADS = 1024;   // threads per row, general instantiation
+constexpr int TK_CAP = 8192;       // its candidate capacity (8 B each -> 64 KB LDS)
+constexpr int TK_THREADS_S = 256;  // threads per row, tile path with k <= 256
+constexpr int TK_CAP_S = 1024;     // its candidate capacity (8 KB LDS); more candidates -> exact path
+constexpr int TK_GROUPS = 4;       // maxima kept per thread: the fast path covers k <= 3 * threads
 constexpr int TK_TILE = SPHIP_TOPK_TILE;   // latents per block maximum (sphip_encoder_preacts)
 constexpr int TK_TCAP = 2048;  // selected-block list capacity
 
@@ -62,6 +69,7 @@ __device__ __forceinline__ void load_keys(const T* row, const uint8_t* keep, int
 
 // block-wide sum of a per-thread count; `slot` alternates between calls so one barrier
 // per call is enough. part = [2][TK_WAVES] in LDS.
+template <int TK_WAVES>
 __device__ __forceinline__ unsigned block_count(unsigned c, unsigned* part, int slot) {
     c = (unsigned)wave_sum_i((int)c);
     unsigned* p = part + slot * TK_WAVES;
@@ -73,12 +81,13 @@ __device__ __forceinline__ unsigned block_count(unsigned c, unsigned* part, int 
     return t;
 }
 
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, int TK_THREADS = sphip::TK_THREADS, int TK_CAP = sphip::TK_CAP>
 __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict__ pre,
                                                           const uint8_t* __restrict__ keep,
                                                           const T* __restrict__ tile_max, int M,
                                                           int k, T* __restrict__ vals,
                                                           int64_t* __restrict__ idx_out) {
+    constexpr int TK_WAVES = TK_THREADS / 64;
     constexpr int V = KeyOf<T>::VEC;
     constexpr int BITS = KeyOf<T>::BITS;
     __shared__ unsigned long long cand[TK_CAP];
@@ -111,7 +120,15 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
         // the k-th largest element from below
         unsigned tmax[TK_GROUPS] = {0u, 0u, 0u, 0u};
         if (by_tile) {
-            for (int t = tid; t < T_; t += TK_THREADS) tmax[0] = max(tmax[0], to_key(tm_row[t * 64]));
+            // chunk c of the block maxima goes to group c % 4: up to 4 * threads blocks keep a
+            // maximum of their own, which puts tau closer to the k-th largest element
+            int c = 0;
+            for (int t = tid; t < T_; t += TK_THREADS, ++c) {
+                const unsigned m = to_key(tm_row[t * 64]);
+                const int grp = c & (TK_GROUPS - 1);
+#pragma unroll
+                for (int r = 0; r < TK_GROUPS; ++r) tmax[r] = (r == grp) ? max(tmax[r], m) : tmax[r];
+            }
         } else {
             int c = 0;
             for (int i = tid * V; i < M; i += span, ++c) {
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
             unsigned mine = 0;
 #pragma unroll
             for (int r = 0; r < TK_GROUPS; ++r) mine += (tmax[r] >= t) ? 1u : 0u;
-            const unsigned c = block_count(mine, part, slot);
+            const unsigned c = block_count<TK_WAVES>(mine, part, slot);
             slot ^= 1;
             if (c >= (unsigned)k) tau = t;
         }
@@ -173,13 +190,25 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
             } else {
                 constexpr int LPT = TK_TILE / V;          // lanes per block: 16 (bf16) / 32 (f32)
                 constexpr int GPW = 64 / LPT;             // blocks per wave instruction
-                for (unsigned g0 = (unsigned)wave * GPW; g0 < nt; g0 += TK_WAVES * GPW) {
-                    const unsigned g = g0 + (unsigned)(lane / LPT);
-                    const int i = g < nt ? (int)tiles[g] * TK_TILE + (lane % LPT) * V : M;
-                    unsigned key[V];
-                    if (i < M) load_keys<T, true>(row, nullptr, i, M, key);
+                // U block loads per lane are issued before the first candidate is pushed (the
+                // list's ballots and LDS atomics would otherwise serialise the loads' latencies)
+                constexpr int U = TK_THREADS >= 1024 ? 1 : 4;
+                for (unsigned g0 = (unsigned)wave * GPW; g0 < nt; g0 += U * TK_WAVES * GPW) {
+                    unsigned key[U][V];
+                    int at[U];
 #pragma unroll
-                    for (int j = 0; j < V; ++j) push(i < M && key[j] >= tau, i < M ? key[j] : 0u, i + j);
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned g = g0 + (unsigned)(u * TK_WAVES * GPW) + (unsigned)(lane / LPT);
+                        at[u] = g < nt ? (int)tiles[g] * TK_TILE + (lane % LPT) * V : M;
+                        if (at[u] < M) load_keys<T, true>(row, nullptr, at[u], M, key[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (g0 + (unsigned)(u * TK_WAVES * GPW) >= nt) break;      // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            push(at[u] < M && key[u][j] >= tau, at[u] < M ? key[u][j] : 0u, at[u] + j);
+                    }
                 }
             }
         } else {
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
 #pragma unroll
             for (int j = 0; j < V; ++j) c += ((ALIGNED || i + j < M) && key[j] >= t) ? 1u : 0u;
         }
-        const unsigned tot = block_count(c, part, slot);
+        const unsigned tot = block_count<TK_WAVES>(c, part, slot);
         slot ^= 1;
         if (tot >= (unsigned)k) kth = t;
     }
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
 #pragma unroll
         for (int j = 0; j < V; ++j) cgt += ((ALIGNED || i + j < M) && key[j] > kth) ? 1u : 0u;
     }
-    const unsigned count_gt = block_count(cgt, part, slot);
+    const unsigned count_gt = block_count<TK_WAVES>(cgt, part, slot);
     slot ^= 1;
     const unsigned need_eq = (unsigned)k - count_gt;
 
@@ -355,7 +384,19 @@ extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, 
     dim3 grid((unsigned)N), block(TK_THREADS);
     const int vec = dtype == SPHIP_BF16 ? 8 : 4;
     const bool aligned = (M % vec == 0) && (((uintptr_t)pre & 15) == 0) && (((uintptr_t)keep_mask & 7) == 0);
-    if (dtype == SPHIP_BF16) {
+    // tile path with few selected latents: four waves per row (the kernel's own by_tile rule
+    // holds for these shapes; SPHIP_TOPK_WIDE=1 keeps the 1024-thread form, A/B switch)
+    const int64_t T_ = cdiv(M, (int64_t)TK_TILE);
+    static const bool wide_only = getenv("SPHIP_TOPK_WIDE") != nullptr;
+    const bool small = aligned && tile_max != nullptr && keep_mask == nullptr && k <= TK_THREADS_S && T_ >= k &&
+                       T_ <= 16 * TK_THREADS_S && !(k >= 256 && M <= 16 * k) && !wide_only;
+    if (small) {
+        dim3 sblock(TK_THREADS_S);
+        if (dtype == SPHIP_BF16)
+            hipLaunchKernelGGL((topk_kernel<bf16_t, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
+        else
+            hipLaunchKernelGGL((topk_kernel<float, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
+    } else if (dtype == SPHIP_BF16) {
         if (aligned)
             hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
         else
