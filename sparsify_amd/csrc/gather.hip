@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void gather_rows_sliced_kernel(const int64_t* 
         const float4 b = *reinterpret_cast<const float4*>(bias + col);
         acc.x += b.x, acc.y += b.y, acc.z += b.z, acc.w += b.w;
     }
-    *reinterpret_cast<float4*>(out + n * (int64_t)D + col) = acc;
+    // written once, read by a later kernel: non-temporal, the table slice keeps the caches
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 t = {acc.x, acc.y, acc.z, acc.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4*>(out + n * (int64_t)D + col));
 }
 
 // Validates idx on the device is not done (cost); the host wrapper guarantees the range

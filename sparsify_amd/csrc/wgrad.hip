@@ -202,8 +202,11 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     if (FUSE && live) {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col + c);
-            wold[c] = t.x, wold[c + 1] = t.y, wold[c + 2] = t.z, wold[c + 3] = t.w;
+            // streamed once: non-temporal, like the stores below, so that the parameter traffic
+            // does not push the resident slice of `rows` out of L2
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gW + (int64_t)j * D + col + c));
+            wold[c] = t[0], wold[c + 1] = t[1], wold[c + 2] = t[2], wold[c + 3] = t[3];
         }
     }
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
@@ -258,14 +261,16 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                     w[e] -= lr * (float)((g > 0.f) - (g < 0.f));
                     sh[c + e] = f32_to_bf16(w[e]);
                 }
-                *reinterpret_cast<f4*>(o + c) = w;
+                __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o + c));
             }
             if (shadow != nullptr) {
                 bf16_t* so = shadow + (int64_t)j * D + col;
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int c = 0; c < C; c += 4)
-                    *reinterpret_cast<uint2*>(so + c) = make_uint2((unsigned)sh[c] | ((unsigned)sh[c + 1] << 16),
-                                                                   (unsigned)sh[c + 2] | ((unsigned)sh[c + 3] << 16));
+                for (int c = 0; c < C; c += 4) {
+                    const u2 t = {(unsigned)sh[c] | ((unsigned)sh[c + 1] << 16), (unsigned)sh[c + 2] | ((unsigned)sh[c + 3] << 16)};
+                    __builtin_nontemporal_store(t, reinterpret_cast<u2*>(so + c));
+                }
             }
         } else {
 #pragma unroll
@@ -345,7 +350,13 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
                                             int slice, int lane, float lr, bf16_t* __restrict__ shadow) {
     const int col = slice * 256 + lane * 4;
     const int beg = seg_begin[j], end = seg_begin[j + 1];
-    const float4 w = DOT ? *reinterpret_cast<const float4*>(W + (int64_t)j * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // W and gW are streamed once: non-temporal, so that they do not displace the resident slice of `rows`
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DOT) {
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(W + (int64_t)j * D + col));
+        w = make_float4(t[0], t[1], t[2], t[3]);
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float bsum = 0.f;
     const RT* rcol = rows + col;
@@ -423,7 +434,8 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
             *reinterpret_cast<uint2*>(shadow + (int64_t)j * D + col) = make_uint2(lo, hi);
         }
     } else {
-        *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
+        const f4 t = {acc.x, acc.y, acc.z, acc.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(gW + (int64_t)j * D + col));
     }
     if (gbias != nullptr && slice == 0 && lane == 0) gbias[j] = bsum;
 }
