@@ -385,7 +385,10 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
         if (n >= N || mcol >= M) continue;
         bf16_t* dst = P + (int64_t)n * ldp + mcol;
         if (vec) {
-            *reinterpret_cast<uint4*>(dst) = v;
+            // 4 GiB written once per launch and read back only in part (top-k): non-temporal, the
+            // operand tiles keep L2
+            const u32x4_t nv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>(dst));
         } else {
             const unsigned w4[4] = {v.x, v.y, v.z, v.w};
             for (int j = 0; j < 8 && mcol + j < M; ++j) dst[j] = (bf16_t)(w4[j >> 1] >> ((j & 1) * 16));
