@@ -38,8 +38,9 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int G_TILE = 256;
 // MFMA groups of 4 issued after an M segment's closing barrier (raising the barrier hides its
-// release latency under the last MFMAs): measured 0 -> 12.1 ms, 1 -> 12.0 ms, 2 -> 12.6 ms
-constexpr int EARLY = 0;
+// release latency under the last MFMAs). A/B on one box, interleaved, with the non-temporal
+// epilogue stores: 0 -> 12.27 ms, 1 -> 12.02 ms (2 was slower: 12.6 against 12.1 ms earlier)
+constexpr int EARLY = 1;
 constexpr int G_BK = 64;                      // bf16 elements per K tile (128 B)
 constexpr int R_X = 0;                        // region offsets inside a K-tile buffer
 constexpr int R_WLO = 256 * 128;              // 32 KiB
