@@ -406,7 +406,8 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ bias,
                                                                  bf16_t* __restrict__ P, int N, int D, int M,
                                                                  int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
-                                                                 int64_t ldp, int tilesT, unsigned* dbg = nullptr) {
+                                                                 int64_t ldp, int tilesT, int bandh,
+                                                                 unsigned* dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned nb = (unsigned)tilesM * (unsigned)tilesN;
     for (unsigned vb = blockIdx.x; vb < nb; vb += gridDim.x) {
@@ -414,10 +415,10 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         const unsigned xcd = vb & 7, slot = vb >> 3;
         const unsigned q = nb >> 3, r = nb & 7;
         const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        const unsigned band = 8u * (unsigned)tilesN;
+        const unsigned band = (unsigned)bandh * (unsigned)tilesN;
         const unsigned g = L / band, within = L % band;
-        const unsigned first = g * 8;
-        const unsigned gsize = min((unsigned)tilesM - first, 8u);
+        const unsigned first = g * (unsigned)bandh;
+        const unsigned gsize = min((unsigned)tilesM - first, (unsigned)bandh);
         gemm256_tile<RELU, DIAG, OUTF>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
                                        tile_max, ldp, tilesT, dbg, smem);
         if (vb + gridDim.x < nb) __syncthreads();      // the next tile's staging overwrites the epilogue area
@@ -430,6 +431,17 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
 // buffer; values 64 k select schedule variant k: 1 no s_setprio, 2 s_setprio 3, 3 DMA issue one
 // MFMA group later, 4 two DMAs per group -- measured 12.32 / 12.37 / 12.40 / 12.94 ms against
 // 12.40 ms for the shipped schedule); benchmarks/gemm_bench.py and gemm_stamps.py drive them.
+// latent tiles per band of the tile walk (SPHIP_GEMM_BAND, A/B switch; 8: the 32 workgroups an
+// XCD runs at a time cover 8 latent x 4 token tiles)
+static int gemm_band() {
+    static const int b = [] {
+        const char* e = getenv("SPHIP_GEMM_BAND");
+        const int v = e ? atoi(e) : 8;
+        return v >= 1 && v <= 64 ? v : 8;
+    }();
+    return b;
+}
+
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
@@ -461,7 +473,7 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         (void)hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             G_LDS_BYTES);                                                                         \
         hipLaunchKernelGGL((encoder_gemm256_kernel<true, DG>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,       \
-                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, dbgp); \
+                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(), dbgp); \
     }
     if (diag == 1) SPHIP_DIAG_LAUNCH(1)
     else if (diag == 2) SPHIP_DIAG_LAUNCH(2)
@@ -489,10 +501,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
 #endif
     if (relu)
         hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band());
     else
         hipLaunchKernelGGL((encoder_gemm256_kernel<false>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT);
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("encoder_preacts(256): launch failed: %s", hipGetErrorString(e));
@@ -519,11 +531,11 @@ int launch_gemm256_f32out(const void* x, const void* W, float* out, int64_t N, i
     if (accumulate)
         hipLaunchKernelGGL((encoder_gemm256_kernel<false, 0, 2>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
                            (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
-                           (bf16_t*)nullptr, ld_out, 0);
+                           (bf16_t*)nullptr, ld_out, 0, gemm_band());
     else
         hipLaunchKernelGGL((encoder_gemm256_kernel<false, 0, 1>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
                            (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
-                           (bf16_t*)nullptr, ld_out, 0);
+                           (bf16_t*)nullptr, ld_out, 0, gemm_band());
     SPHIP_CHECK_LAUNCH("gemm_bf16_f32acc");
     return SPHIP_OK;
 }
