@@ -213,30 +213,44 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
     // Software pipeline: the packed entries of batch b+1 are requested before the row pieces
-    // of batch b are consumed, so a batch costs one L2 round trip instead of two.
+    // of batch b are consumed, so a batch costs one L2 round trip instead of two. Full batches
+    // run without per-entry guards (the lane groups of a wave differ in segment length, and
+    // every guarded load is a branch on the exec mask): entry positions past the segment are
+    // clamped to its last entry when they are prefetched and only the final partial batch checks.
+    if (!live) beg = end = 0;
     constexpr int U = 4;
+    const int last = max(end - 1, 0);
     uint2 nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) nxt[u] = (beg + u < end) ? packed[beg + u] : make_uint2(0u, 0u);
-    for (int p = beg; p < end; p += U) {
+    for (int u = 0; u < U; ++u) nxt[u] = packed[min(beg + u, last)];
+    int p = beg;
+    for (; p + U <= end; p += U) {
         uint2 pk[U];
         float v[U][C];
 #pragma unroll
         for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if ((p + u < end) && live) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
-            else {
+        for (int u = 0; u < U; ++u) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
 #pragma unroll
-                for (int c = 0; c < C; ++c) v[u][c] = 0.f;
-            }
+        for (int u = 0; u < U; ++u) nxt[u] = packed[min(p + U + u, last)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
+            const float cf = __uint_as_float(pk[u].y);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
+            bsum += cf;
+        }
+    }
+    if (p < end) {
+        float v[U][C];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) {
+            if (p + u < end) Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C), v[u]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) nxt[u] = (p + U + u < end) ? packed[p + U + u] : make_uint2(0u, 0u);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (p + u < end) {     // keeps the exact sequential fma chain of the full-row kernel
-                const float cf = __uint_as_float(pk[u].y);
+        for (int u = 0; u < U - 1; ++u) {
+            if (p + u < end) {
+                const float cf = __uint_as_float(nxt[u].y);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
                 bsum += cf;
