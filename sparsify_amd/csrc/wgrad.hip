@@ -218,7 +218,10 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // every guarded load is a branch on the exec mask): entry positions past the segment are
     // clamped to its last entry when they are prefetched and only the final partial batch checks.
     if (!live) beg = end = 0;
-    constexpr int U = 4;
+#ifndef SPHIP_SLICED_U
+#define SPHIP_SLICED_U 6
+#endif
+    constexpr int U = SPHIP_SLICED_U;
     const int last = max(end - 1, 0);
     uint2 nxt[U];
 #pragma unroll
