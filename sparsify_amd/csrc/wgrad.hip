@@ -212,7 +212,22 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
-    // Software pipeline: the packed entries of batch b+1 are requested before the row pieces
+    // The 32 latents of a workgroup are consecutive, so their segments are one contiguous range
+    // of `packed` (~32 N k / M entries): it is staged in LDS with coalesced loads, one round
+    // trip for the whole workgroup, instead of every lane group fetching its entries 8 bytes at
+    // a time from the Infinity Cache once per batch (the entry list is re-read for every
+    // slice and does not stay in L2; that fetch, not the L2-resident row pieces, was what a
+    // batch waited for). Ranges beyond the staging area (skewed latents) read global memory.
+    constexpr int STAGE = 2048;                         // entries (16 KiB)
+    __shared__ uint2 sh_pk[STAGE];
+    const int j0 = min((int)lblock * 32, M), j1 = min((int)lblock * 32 + 32, M);
+    const int rb = seg_begin[j0], re = seg_begin[j1];   // block-uniform
+    const bool staged = re - rb <= STAGE;
+    if (staged) {
+        for (int i = threadIdx.x; i < re - rb; i += 256) sh_pk[i] = packed[rb + i];
+        __syncthreads();
+    }
+    // Software pipeline: the entries of batch b+1 are requested before the row pieces
     // of batch b are consumed, so a batch costs one L2 round trip instead of two. Full batches
     // run without per-entry guards (the lane groups of a wave differ in segment length, and
     // every guarded load is a branch on the exec mask): entry positions past the segment are
@@ -222,43 +237,49 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 #define SPHIP_SLICED_U 6
 #endif
     constexpr int U = SPHIP_SLICED_U;
-    const int last = max(end - 1, 0);
-    uint2 nxt[U];
+    auto run = [&](auto entry) {
+        const int last = max(end - 1, 0);
+        uint2 nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) nxt[u] = packed[min(beg + u, last)];
-    int p = beg;
-    for (; p + U <= end; p += U) {
-        uint2 pk[U];
-        float v[U][C];
+        for (int u = 0; u < U; ++u) nxt[u] = entry(min(beg + u, last));
+        int p = beg;
+        for (; p + U <= end; p += U) {
+            uint2 pk[U];
+            float v[U][C];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pk[u] = nxt[u];
+            for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < U; ++u) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
+            for (int u = 0; u < U; ++u) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) nxt[u] = packed[min(p + U + u, last)];
+            for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
 #pragma unroll
-        for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
-            const float cf = __uint_as_float(pk[u].y);
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
-            bsum += cf;
-        }
-    }
-    if (p < end) {
-        float v[U][C];
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u) {
-            if (p + u < end) Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C), v[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u) {
-            if (p + u < end) {
-                const float cf = __uint_as_float(nxt[u].y);
+            for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
+                const float cf = __uint_as_float(pk[u].y);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
                 bsum += cf;
             }
         }
+        if (p < end) {
+            float v[U][C];
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (p + u < end) Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C), v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (p + u < end) {
+                    const float cf = __uint_as_float(nxt[u].y);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
+                    bsum += cf;
+                }
+            }
+        }
+    };
+    if (end > beg) {
+        if (staged) run([&](int pos) { return sh_pk[pos - rb]; });
+        else run([&](int pos) { return packed[pos]; });
     }
     if (live) {
         if (row_shift != nullptr) {
