@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // clamped to its last entry when they are prefetched and only the final partial batch checks.
     if (!live) beg = end = 0;
 #ifndef SPHIP_SLICED_U
-#define SPHIP_SLICED_U 6
+#define SPHIP_SLICED_U 4
 #endif
     constexpr int U = SPHIP_SLICED_U;
     auto run = [&](auto entry) {
