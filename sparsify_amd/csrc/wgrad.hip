@@ -401,15 +401,21 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
     float* sl = slab + (int64_t)slice * E;
 
     constexpr int U = 8;
+    // the segment's entries come in with one coalesced load per 64 (lane l holds entry p0 + l)
+    // and reach the batches through v_readlane: a batch then waits for its row loads only, not
+    // for a scalar fetch of its entries from the Infinity Cache first
+    uint2 ent = make_uint2(0u, 0u);
     for (int p = beg; p < end; p += U) {
+        const int q = (p - beg) & 63;                // wave-uniform; U divides 64
+        if (q == 0) ent = (p + lane < end) ? packed[p + lane] : make_uint2(0u, 0u);
         float c[U];
         float4 r[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (p + u < end) {                       // wave-uniform
-                const uint2 pk = packed[p + u];
-                c[u] = __uint_as_float(pk.y);
-                r[u] = load4(rcol + (int64_t)fastdiv(pk.x, kdiv) * D);
+                const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)ent.x, q + u);
+                c[u] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ent.y, q + u));
+                r[u] = load4(rcol + (int64_t)fastdiv(ex, kdiv) * D);
             } else {
                 c[u] = 0.f;
                 r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
