@@ -387,7 +387,7 @@ extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, 
     // tile path with few selected latents: four waves per row (the kernel's own by_tile rule
     // holds for these shapes; SPHIP_TOPK_WIDE=1 keeps the 1024-thread form, A/B switch)
     const int64_t T_ = cdiv(M, (int64_t)TK_TILE);
-    static const bool wide_only = getenv("SPHIP_TOPK_WIDE") != nullptr;
+    const bool wide_only = getenv("SPHIP_TOPK_WIDE") != nullptr;
     const bool small = aligned && tile_max != nullptr && keep_mask == nullptr && k <= TK_THREADS_S && T_ >= k &&
                        T_ <= 16 * TK_THREADS_S && !(k >= 256 && M <= 16 * k) && !wide_only;
     if (small) {

@@ -164,6 +164,44 @@ def test_topk_ties_and_degenerate_rows(device, dtype):
     assert torch.equal(v2, vals) and torch.equal(i2, idx)
 
 
+def _block_maxima(pre, tile=128):
+    """tile_max in the layout sphip_encoder_preacts writes: [n // 64, t, n % 64]."""
+    N, M = pre.shape
+    T = -(-M // tile)
+    padded = torch.full((-(-N // 64) * 64, T * tile), float("-inf"), dtype=torch.float32)
+    padded[:N, :M] = pre.float()
+    tm = padded.reshape(-1, 64, T, tile).amax(-1)              # [N/64, 64, T]
+    return tm.permute(0, 2, 1).contiguous().to(pre.dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("M,k", [(8192, 64), (32768, 192), (4096, 32)])
+def test_topk_block_maxima_path_with_ties(device, monkeypatch, dtype, wide, M, k):
+    """Degenerate rows through the block-maxima path, four waves per row (k <= 256) and 1024
+    threads per row: ties overflow the
+    candidate list and must fall through to the exact path with the lowest-index rule."""
+    from sparsify_amd import ops
+    torch.manual_seed(M + k)
+    rows = [
+        torch.zeros(M),
+        torch.cat([torch.arange(10.0) + 1, torch.zeros(M - 10)]),
+        torch.arange(M, dtype=torch.float32) / 64,
+        torch.full((M,), 3.0),
+        torch.randint(0, 4, (M,)).float(),
+        torch.randn(M).clamp_min(0),
+        torch.randn(M).clamp_min(0) * (torch.rand(M) < 0.001),      # fewer positives than k
+    ]
+    pre = torch.stack(rows).to(dtype)
+    if wide:
+        monkeypatch.setenv("SPHIP_TOPK_WIDE", "1")
+    vals, idx = ops.topk(dev(pre), k, tile_max=dev(_block_maxima(pre)))
+    check_topk(pre, k, vals, idx)
+    assert torch.equal(idx[0].cpu().sort().values, torch.arange(k))
+    v0, i0 = ops.topk(dev(pre), k)                                   # full-row sweep: same selection
+    assert torch.equal(i0.sort(-1).values, idx.sort(-1).values)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,k,frac", [(4096, 24, 0.33), (4096, 2048, 0.33), (24576, 384, 0.1), (512, 100, 0.1),
                                       (131072, 2048, 0.1), (131072, 2048, 0.01)])
