@@ -111,6 +111,28 @@ int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff, int coeff_
                                const float* table, const float* bias, float* out, int64_t N,
                                int64_t k, int64_t M, int64_t D, void* stream);
 
+/* The same decode (utils.py:81-90, xformers.py:9-53) for tables far beyond the caches, as an
+ * L2-resident gather: the latents are cut into blocks of 16384 rows, one launch per block
+ * gathers 128-byte row pieces from 2 MiB of the table per XCD and adds its partial sums to
+ * out (the first launch writes bias + partial). Same arguments as sphip_gather_rows_weighted
+ * plus a workspace of sphip_gather_l2_workspace_bytes(N, k, M, D) bytes (256-byte aligned);
+ * that query returns 0 when the shape is not eligible (small tables, D % 32 != 0, fewer than
+ * 8 slots per token and block, ...): call sphip_gather_rows_weighted then. The fp32 sum runs
+ * block by block, slots in order inside a block (deterministic; differs from the slot-order
+ * sum of sphip_gather_rows_weighted by rounding only). Negative indices are skipped. */
+size_t sphip_gather_l2_workspace_bytes(int64_t N, int64_t k, int64_t M, int64_t D);
+/* table_slice_major: NULL, or the copy of table that sphip_slice_major_f32 writes. The gather then
+ * reads that copy: in the row-major table the 128-byte pieces of a column slice lie D*4 bytes
+ * apart, a power-of-two stride that maps a latent block onto a few L2 sets (hit rate 27 %
+ * measured); in the copy they are contiguous. */
+int sphip_gather_rows_weighted_l2(const int64_t* idx, const void* coeff, int coeff_dtype,
+                                  const float* table, const float* table_slice_major,
+                                  const float* bias, float* out, int64_t N, int64_t k, int64_t M,
+                                  int64_t D, void* workspace, size_t workspace_bytes, void* stream);
+/* src (R, D) fp32 row-major -> dst [D/32][R][32]: every 128-byte column slice of the table as one
+ * contiguous R x 128 B block (no reference counterpart: a layout for the gather above). */
+int sphip_slice_major_f32(const float* src, float* dst, int64_t R, int64_t D, void* stream);
+
 /* count_per_embedding_k + cumsum + map_embeddings_and_outputs_k, xformers.py:56-85,139-163:
  * counting sort of the N*k (token,slot) entries by latent id.
  *   seg_begin (M+1) int32: entries of latent j are perm[seg_begin[j] : seg_begin[j+1]]

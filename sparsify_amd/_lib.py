@@ -35,6 +35,9 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_topk": (_I, [_P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_groupmax": (_I, [_P, _I, _L, _L, _L, _P, _P, _P]),
     "sphip_gather_rows_weighted": (_I, [_P, _P, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
+    "sphip_gather_l2_workspace_bytes": (_Z, [_L, _L, _L, _L]),
+    "sphip_gather_rows_weighted_l2": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P]),
+    "sphip_slice_major_f32": (_I, [_P, _P, _L, _L, _P]),
     "sphip_segments_workspace_bytes": (_Z, [_L, _L, _L]),
     "sphip_build_latent_segments": (_I, [_P, _L, _L, _L, _P, _P, _P, _Z, _P]),
     "sphip_weight_grad_workspace_bytes": (_Z, [_L, _L, _L]),

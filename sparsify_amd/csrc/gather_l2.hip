@@ -1,0 +1,252 @@
+// L2-resident sparse decode for tables far larger than the caches:
+//   out[n,:] = sum_s coeff[n,s] * table[idx[n,s],:]  (+ bias)
+// Reference: decoder_impl / eager_decode, sparsify/utils.py:81-90; embedding_bag_k,
+// sparsify/xformers.py:9-53 (same contract as sphip_gather_rows_weighted, gather.hip).
+//
+// The token-major kernels of gather.hip read k random 1-KiB row slices per (token, slice) out
+// of a 128 MiB column slice that only the Infinity Cache holds: 7.5 TB/s, that cache's ceiling
+// for random rows. Here the working set of the moment is made to fit the 4 MiB L2 of an XCD:
+// the latents are cut into B blocks of BLOCK_ROWS rows, and a launch handles ONE latent block
+// for all tokens and all 128-byte column slices, the slices dealt to the XCDs, so that an XCD
+// gathers from BLOCK_ROWS x 128 B = 2 MiB of the table at a time. B launches follow each other
+// on the stream; the first writes out = bias + partial sum, the others add theirs, so the
+// sum has a fixed order (block by block, slots in order inside a block) and needs no atomics.
+//
+//   bucket_kernel<false>: one wave per token counts its slots per latent block
+//   exclusive scan over the (block, token) counts -> start of every (block, token) list
+//   bucket_kernel<true> : writes {latent, coeff} of every slot to its list (slot order kept)
+//   gather_l2_kernel    : 8 lanes per (token, 128-B slice); the 32 tokens of a workgroup own one
+//                         contiguous range of the block's list, staged in LDS by coalesced
+//                         loads; four row pieces in flight per lane group, full batches
+//                         without per-entry guards (as seg_wgrad_sliced_kernel, wgrad.hip)
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace sphip {
+
+void launch_exclusive_scan(unsigned* a, int64_t n, unsigned* chunk_tot, hipStream_t s);   // segments.hip
+
+constexpr int L2_BLOCK_ROWS = 16384;   // latents per block: 2 MiB of 128-byte row pieces
+constexpr int L2_MAX_BLOCKS = 32;
+constexpr int L2_STAGE = 2048;         // staged list entries per workgroup (16 KiB)
+
+struct L2Plan {
+    int blocks;
+    size_t off_start, off_spine, off_list, total;
+};
+
+static L2Plan l2_plan(int64_t N, int64_t k, int64_t M) {
+    L2Plan p;
+    p.blocks = (int)cdiv(M, L2_BLOCK_ROWS);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const int64_t cells = (int64_t)p.blocks * N + 1;
+    p.off_start = take((size_t)cells * 4);
+    p.off_spine = take((size_t)cdiv(cells, 4096) * 4 + 4);
+    p.off_list = take((size_t)(N * k) * 8);
+    p.total = o;
+    return p;
+}
+
+static bool l2_eligible(int64_t N, int64_t k, int64_t M, int64_t D) {
+    if (D % 32 != 0 || N * k >= (1ll << 31) || M >= (1ll << 31) || N >= (1ll << 26)) return false;
+    const int64_t B = cdiv(M, L2_BLOCK_ROWS);
+    // worth it when the table is beyond the Infinity Cache, every (token, block) list still
+    // holds a few entries, and every table row is used several times per launch
+    return B >= 2 && B <= L2_MAX_BLOCKS && M * D * 4 > (512ll << 20) && k >= 8 * B && N * k >= 8 * M;
+}
+
+// One wave per token. SCATTER = false: start[b * N + n] = number of the token's slots whose
+// latent lies in block b. SCATTER = true (start now holds the scanned offsets): the slots are
+// written to their lists, in slot order. Slots with a negative or out-of-range index
+// (inactive: latent owned by another shard) belong to no block.
+template <typename CT, bool SCATTER>
+__global__ __launch_bounds__(256) void bucket_kernel(const int64_t* __restrict__ idx, const CT* __restrict__ coeff,
+                                                     int64_t N, int k, int64_t M, int B, unsigned* __restrict__ start,
+                                                     uint2* __restrict__ list) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    unsigned mine = 0;                                   // lane b: count / running offset of block b
+    if (SCATTER && lane < B) mine = start[(int64_t)lane * N + n];
+    for (int s0 = 0; s0 < k; s0 += 64) {
+        const int s = s0 + lane;
+        int64_t j = -1;
+        if (s < k) j = idx[n * k + s];
+        const int bl = (j < 0 || j >= M) ? -1 : (int)(j / L2_BLOCK_ROWS);
+        unsigned pos = 0;
+        for (int b = 0; b < B; ++b) {
+            const unsigned long long m = __ballot(bl == b);
+            if (SCATTER) {
+                const unsigned base = (unsigned)__shfl((int)mine, b, 64);
+                if (bl == b) pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            }
+            if (lane == b) mine += (unsigned)__popcll(m);
+        }
+        if (SCATTER && bl >= 0)
+            list[pos] = make_uint2((unsigned)j, __float_as_uint(Elem<CT>::load(coeff, n * k + s)));
+    }
+    if (!SCATTER && lane < B) start[(int64_t)lane * N + n] = mine;
+}
+
+// SM: `table` is the slice-major copy [D/32][M][32] (sphip_slice_major_f32): the row pieces of a
+// slice are then contiguous. In the row-major table they lie D*4 bytes apart, a power-of-two
+// stride that maps a latent block's pieces onto a few L2 sets (measured: L2 hit rate 27 %, the
+// gather then runs at the Infinity Cache's rate like the token-major kernels).
+template <bool FIRST, bool SM>
+__global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict__ list,
+                                                        const unsigned* __restrict__ start,   // of this block
+                                                        const float* __restrict__ table, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int N, int D, int64_t M,
+                                                        int groups_per_slice, int num_slices) {
+    // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
+    const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const unsigned slice = xcd + 8 * (local / (unsigned)groups_per_slice);
+    if (slice >= (unsigned)num_slices) return;
+    const int n0 = (int)(local % (unsigned)groups_per_slice) * 32;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+    const int n = n0 + (threadIdx.x >> 6) * 8 + grp;
+    const int col = (int)slice * 32 + sub * 4;
+    const bool live = n < N;
+    int beg = 0, end = 0;
+    if (live) { beg = (int)start[n]; end = (int)start[n + 1]; }
+
+    __shared__ uint2 sh[L2_STAGE];
+    const int rb = (int)start[n0], re = (int)start[min(n0 + 32, N)];     // block-uniform
+    const bool staged = re - rb <= L2_STAGE;
+    if (staged) {
+        for (int i = threadIdx.x; i < re - rb; i += 256) sh[i] = list[rb + i];
+        __syncthreads();
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 prev = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (FIRST) {
+            if (bias != nullptr) prev = *reinterpret_cast<const f4*>(bias + col);
+        } else {
+            prev = __builtin_nontemporal_load(reinterpret_cast<const f4*>(out + (int64_t)n * D + col));
+        }
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // piece of latent j: tcol + j * stride
+    const float* tcol = SM ? table + ((int64_t)slice * M) * 32 + sub * 4 : table + col;
+    const int64_t stride = SM ? 32 : D;
+    constexpr int U = 4;
+    auto run = [&](auto entry) {
+        const int last = max(end - 1, 0);
+        uint2 nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = entry(min(beg + u, last));
+        int p = beg;
+        for (; p + U <= end; p += U) {
+            uint2 pk[U];
+            float4 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pk[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = load4(tcol + (int64_t)pk[u].x * stride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float cf = __uint_as_float(pk[u].y);
+                acc[0] = fmaf(cf, r[u].x, acc[0]);
+                acc[1] = fmaf(cf, r[u].y, acc[1]);
+                acc[2] = fmaf(cf, r[u].z, acc[2]);
+                acc[3] = fmaf(cf, r[u].w, acc[3]);
+            }
+        }
+        if (p < end) {
+            float4 r[U];
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (p + u < end) r[u] = load4(tcol + (int64_t)nxt[u].x * stride);
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (p + u < end) {
+                    const float cf = __uint_as_float(nxt[u].y);
+                    acc[0] = fmaf(cf, r[u].x, acc[0]);
+                    acc[1] = fmaf(cf, r[u].y, acc[1]);
+                    acc[2] = fmaf(cf, r[u].z, acc[2]);
+                    acc[3] = fmaf(cf, r[u].w, acc[3]);
+                }
+            }
+        }
+    };
+    if (end > beg) {
+        if (staged) run([&](int pos) { return sh[pos - rb]; });
+        else run([&](int pos) { return list[pos]; });
+    }
+    if (live) {
+        const f4 o = {prev[0] + acc[0], prev[1] + acc[1], prev[2] + acc[2], prev[3] + acc[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<f4*>(out + (int64_t)n * D + col));
+    }
+}
+
+}  // namespace sphip
+
+extern "C" size_t sphip_gather_l2_workspace_bytes(int64_t N, int64_t k, int64_t M, int64_t D) {
+    using namespace sphip;
+    if (N <= 0 || k <= 0 || M <= 0 || D <= 0 || !l2_eligible(N, k, M, D)) return 0;
+    return l2_plan(N, k, M).total;
+}
+
+extern "C" int sphip_gather_rows_weighted_l2(const int64_t* idx, const void* coeff, int coeff_dtype, const float* table,
+                                             const float* table_slice_major, const float* bias, float* out, int64_t N,
+                                             int64_t k, int64_t M, int64_t D,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(coeff_dtype), SPHIP_EINVAL, "gather_rows_weighted_l2: bad coeff dtype %d", coeff_dtype);
+    SPHIP_REQUIRE(idx && coeff && table && out && workspace, SPHIP_EINVAL, "gather_rows_weighted_l2: null pointer");
+    SPHIP_REQUIRE(N > 0 && k > 0 && M > 0 && D > 0, SPHIP_EINVAL, "gather_rows_weighted_l2: empty shape");
+    SPHIP_REQUIRE(l2_eligible(N, k, M, D), SPHIP_EUNSUPPORTED,
+                  "gather_rows_weighted_l2: shape N=%lld k=%lld M=%lld D=%lld is not eligible "
+                  "(sphip_gather_l2_workspace_bytes returns 0 for it): use sphip_gather_rows_weighted",
+                  (long long)N, (long long)k, (long long)M, (long long)D);
+    SPHIP_REQUIRE((((uintptr_t)table | (uintptr_t)table_slice_major | (uintptr_t)out | (uintptr_t)bias) & 15) == 0,
+                  SPHIP_EINVAL, "gather_rows_weighted_l2: table, bias and out must be 16-byte aligned");
+    const L2Plan p = l2_plan(N, k, M);
+    SPHIP_REQUIRE(workspace_bytes >= p.total, SPHIP_EWORKSPACE, "gather_rows_weighted_l2: workspace %zu < %zu bytes",
+                  workspace_bytes, p.total);
+    SPHIP_REQUIRE(((uintptr_t)workspace & 255) == 0, SPHIP_EINVAL, "gather_rows_weighted_l2: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    unsigned* start = (unsigned*)(ws + p.off_start);
+    unsigned* spine = (unsigned*)(ws + p.off_spine);
+    uint2* list = (uint2*)(ws + p.off_list);
+    const int64_t cells = (int64_t)p.blocks * N + 1;
+    // the cell after the last (block, token) pair counts nothing: after the scan it holds the total
+    SPHIP_REQUIRE(hipMemsetAsync(start + cells - 1, 0, 4, s) == hipSuccess, SPHIP_ELAUNCH,
+                  "gather_rows_weighted_l2: memset failed");
+    dim3 tgrid((unsigned)cdiv(N, 4)), block(256);
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((bucket_kernel<float, false>), tgrid, block, 0, s, idx, (const float*)coeff, N, (int)k, M, p.blocks, start, list);
+    else
+        hipLaunchKernelGGL((bucket_kernel<bf16_t, false>), tgrid, block, 0, s, idx, (const bf16_t*)coeff, N, (int)k, M, p.blocks, start, list);
+    launch_exclusive_scan(start, cells, spine, s);
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((bucket_kernel<float, true>), tgrid, block, 0, s, idx, (const float*)coeff, N, (int)k, M, p.blocks, start, list);
+    else
+        hipLaunchKernelGGL((bucket_kernel<bf16_t, true>), tgrid, block, 0, s, idx, (const bf16_t*)coeff, N, (int)k, M, p.blocks, start, list);
+    const int num_slices = (int)(D / 32);
+    const int gps = (int)cdiv(N, 32);
+    const int64_t nblocks = cdiv(num_slices, 8) * gps * 8;
+    SPHIP_REQUIRE(nblocks < (1ll << 31), SPHIP_EUNSUPPORTED, "gather_rows_weighted_l2: grid too large");
+    const bool sm = table_slice_major != nullptr;
+    const float* tb = sm ? table_slice_major : table;
+    for (int b = 0; b < p.blocks; ++b) {
+        const unsigned* st = start + (int64_t)b * N;
+        dim3 grid((unsigned)nblocks);
+#define SPHIP_L2_LAUNCH(F, S) \
+    hipLaunchKernelGGL((gather_l2_kernel<F, S>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices)
+        if (b == 0 && sm) SPHIP_L2_LAUNCH(true, true);
+        else if (b == 0) SPHIP_L2_LAUNCH(true, false);
+        else if (sm) SPHIP_L2_LAUNCH(false, true);
+        else SPHIP_L2_LAUNCH(false, false);
+#undef SPHIP_L2_LAUNCH
+    }
+    SPHIP_CHECK_LAUNCH("gather_rows_weighted_l2");
+    return SPHIP_OK;
+}

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(unsigned* __restrict__
     }
 }
 
-static void launch_exclusive_scan(unsigned* a, int64_t n, unsigned* chunk_tot, hipStream_t s) {
+// also used by gather_l2.hip
+void launch_exclusive_scan(unsigned* a, int64_t n, unsigned* chunk_tot, hipStream_t s) {
     const int64_t nchunks = cdiv(n, SCAN_CHUNK);
     hipLaunchKernelGGL(scan_totals_kernel, dim3((unsigned)nchunks), dim3(1024), 0, s, a, n, chunk_tot);
     hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, s, chunk_tot, nchunks);

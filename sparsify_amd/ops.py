@@ -6,6 +6,8 @@ host and then passes raw pointers; nothing in this module computes with torch op
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -207,7 +209,35 @@ def groupmax(pre: Tensor, k: int):
 
 
 # ------------------------------------------------------------------ gathers / segments
-def gather_rows_weighted(idx: Tensor, coeff: Tensor, table: Tensor, bias: Tensor | None = None) -> Tensor:
+_slice_major: dict[int, tuple] = {}
+
+
+def slice_major_copy(table: Tensor) -> Tensor:
+    """[D/32][M][32] copy of a (M, D) fp32 table (sphip_slice_major_f32), refreshed only when the
+    table's version changed -- the optimizer steps bump it, like the bf16 shadow of encoder.weight."""
+    key = table.data_ptr()
+    hit = _slice_major.get(key)
+    state = (table._version, tuple(table.shape))
+    if hit is not None and hit[0] == state:
+        return hit[1]
+    M, D = table.shape
+    buf = hit[1] if hit is not None and hit[1].numel() == table.numel() else torch.empty(D // 32, M, 32, dtype=torch.float32,
+                                                                                        device=table.device)
+    check(_lib.load().sphip_slice_major_f32(table.data_ptr(), buf.data_ptr(), M, D, _stream(table)), "sphip_slice_major_f32")
+    if len(_slice_major) > 8:
+        _slice_major.clear()
+    _slice_major[key] = (state, buf)
+    return buf
+
+
+def slice_major_copy_of(table: Tensor, owner: Tensor | None) -> Tensor | None:
+    if owner is None or owner.data_ptr() != table.data_ptr() or owner.shape != table.shape:
+        return None
+    return slice_major_copy(owner)
+
+
+def gather_rows_weighted(idx: Tensor, coeff: Tensor, table: Tensor, bias: Tensor | None = None,
+                         table_owner: Tensor | None = None) -> Tensor:
     """out[n] = sum_s coeff[n,s] * table[idx[n,s]] (+ bias); utils.py:81-85 / fused_encoder.py:58-64."""
     _req(idx, "indices", torch.int64, 2)
     _req(coeff, "coeff", ndim=2)
@@ -219,10 +249,23 @@ def gather_rows_weighted(idx: Tensor, coeff: Tensor, table: Tensor, bias: Tensor
     if coeff.shape != idx.shape:
         raise ValueError(f"coeff {tuple(coeff.shape)} vs indices {tuple(idx.shape)}")
     out = torch.empty(N, D, dtype=torch.float32, device=table.device)
+    lib = _lib.load()
+    # tables far beyond the caches: the L2-resident form (gather_l2.hip); SPHIP_GATHER=full|sliced keeps
+    # the token-major kernels (A/B runs, bitwise comparisons between them)
+    l2_bytes = lib.sphip_gather_l2_workspace_bytes(N, k, M, D) if os.environ.get("SPHIP_GATHER", "l2") == "l2" else 0
     _ev = timer.start("sphip_gather_rows_weighted", table)
-    check(_lib.load().sphip_gather_rows_weighted(idx.data_ptr(), coeff.data_ptr(), _dt(coeff), table.data_ptr(),
-                                                _ptr(bias), out.data_ptr(), N, k, M, D, _stream(table)),
-          "sphip_gather_rows_weighted")
+    if l2_bytes:
+        ws = _workspace(table.device, l2_bytes, "gather_l2")
+        # table_owner: the tensor whose version says when `table` (a detached view of it) changed;
+        # without it the row-major table is read directly (no copy to keep current)
+        sm = slice_major_copy_of(table, table_owner) if os.environ.get("SPHIP_GATHER_SM", "1") != "0" else None
+        check(lib.sphip_gather_rows_weighted_l2(idx.data_ptr(), coeff.data_ptr(), _dt(coeff), table.data_ptr(), _ptr(sm),
+                                                _ptr(bias), out.data_ptr(), N, k, M, D, ws.data_ptr(), ws.numel(),
+                                                _stream(table)), "sphip_gather_rows_weighted_l2")
+    else:
+        check(lib.sphip_gather_rows_weighted(idx.data_ptr(), coeff.data_ptr(), _dt(coeff), table.data_ptr(),
+                                             _ptr(bias), out.data_ptr(), N, k, M, D, _stream(table)),
+              "sphip_gather_rows_weighted")
     timer.stop(_ev, table)
     return out
 

@@ -25,7 +25,7 @@ class SparseDecode(torch.autograd.Function):
             ctx.set_materialize_grads(False)
             return torch.empty(0, w.shape[1], dtype=torch.float32, device=w.device)
         out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
-                                       None if bias is None else bias.detach())
+                                       None if bias is None else bias.detach(), table_owner=weight)
         ctx.save_for_backward(indices, weight, per_sample_weights)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)

@@ -281,6 +281,44 @@ def test_topk_with_block_maxima(device, monkeypatch, N, D, M, k, gemm, relu):
     assert torch.equal(i2, i3) and torch.equal(v2, v3)
 
 
+@pytest.mark.parametrize("N,k,M,D,cdtype,bias", [(2048, 192, 49152, 4096, torch.bfloat16, True),
+                                                 (2077, 200, 40000, 4096, torch.float32, False)])
+def test_gather_l2_resident_form(device, monkeypatch, N, k, M, D, cdtype, bias):
+    """The L2-resident decode (gather_l2.hip: latent blocks, bucketed slot lists) against the
+    token-major kernel on the same inputs; sums differ in order only. Ragged N, a last latent block
+    that is not full, inactive (negative) slots."""
+    from sparsify_amd import _lib, ops
+    assert _lib.load().sphip_gather_l2_workspace_bytes(N, k, M, D) > 0
+    assert _lib.load().sphip_gather_l2_workspace_bytes(N, 8, M, D) == 0          # too few slots per block
+    assert _lib.load().sphip_gather_l2_workspace_bytes(N, k, 4096, D) == 0       # table fits the caches
+    g = torch.Generator(device="cuda").manual_seed(N + k)
+    table = torch.randn(M, D, device="cuda", generator=g)
+    idx = torch.randint(0, M, (N, k), device="cuda", generator=g)
+    idx[::7, ::5] = -1                                                            # slots of another shard
+    idx[3] = torch.arange(k, device="cuda") + (M - k)                            # one block only
+    idx[5] = -1                                                                   # a token without slots
+    coeff = torch.randn(N, k, device="cuda", generator=g).to(cdtype)
+    b = torch.randn(D, device="cuda", generator=g) if bias else None
+    monkeypatch.setenv("SPHIP_GATHER", "l2")
+    out = ops.gather_rows_weighted(idx, coeff, table, b)                          # row-major table
+    again = ops.gather_rows_weighted(idx, coeff, table, b)
+    assert torch.equal(out, again)                                                # deterministic
+    via_copy = ops.gather_rows_weighted(idx, coeff, table, b, table_owner=table)  # slice-major copy
+    assert torch.equal(out, via_copy)                                             # same sums, same order
+    sm = ops.slice_major_copy(table)
+    assert sm.shape == (D // 32, M, 32) and torch.equal(sm, table.view(M, D // 32, 32).transpose(0, 1))
+    table[11] += 1.0                                                              # version bump -> refreshed copy
+    assert torch.equal(ops.slice_major_copy(table)[:, 11], table[11].view(D // 32, 32))
+    table[11] -= 1.0
+    monkeypatch.setenv("SPHIP_GATHER", "sliced")
+    ref = ops.gather_rows_weighted(idx, coeff, table, b)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    if bias:
+        assert torch.equal(out[5], b)
+    else:
+        assert not out[5].any()
+
+
 @pytest.mark.parametrize("N,k,M,D", [(7, 13, 300, 256), (130, 192, 4096, 1024), (33, 8, 64, 4096)])
 @pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
 def test_gather_sliced_kernel_matches_full(device, monkeypatch, N, k, M, D, cdtype):
