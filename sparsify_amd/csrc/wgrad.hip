@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 // SignSGD to it (sign_sgd.py:23: p -= lr * sign(g)) and refreshes the bf16 shadow, so the
 // (M, D) gradient is neither written nor read back by an optimizer pass
 // (sphip_segmented_weight_grad_signsgd).
-template <typename RT, bool FUSE = false>
+// DOT (fp32 rows): W is the table the rows were decoded with; the kernel also leaves, per slice,
+// the partial dot product <rows[n, slice], W[j, slice]> of every entry in slab[slice][position]
+// (8-lane butterfly per entry, lanes 0..3 of a group store the four entries of a batch as 16
+// contiguous bytes); seg_dcoeff_bounded_kernel sums the slices in order.
+template <typename RT, bool FUSE = false, bool DOT = false>
 __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
@@ -172,7 +176,9 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                                                                int64_t N, int M, int D, int blocks_per_slice,
                                                                int num_slices, float lr = 0.f,
                                                                bf16_t* __restrict__ shadow = nullptr,
-                                                               const int* __restrict__ skew = nullptr, int skew_T = 0) {
+                                                               const int* __restrict__ skew = nullptr, int skew_T = 0,
+                                                               const float* __restrict__ Wdot = nullptr,
+                                                               float* __restrict__ slab = nullptr, int64_t E = 0) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // a workgroup holds 32 latents for as long as its longest segment lasts: with `skew` set,
@@ -209,6 +215,35 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             wold[c] = t[0], wold[c + 1] = t[1], wold[c + 2] = t[2], wold[c + 3] = t[3];
         }
     }
+    float wdot[DOT ? C : 1];
+    if (DOT) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) wdot[c] = 0.f;
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(Wdot + (int64_t)j * D + col + c));
+                wdot[c] = t[0], wdot[c + 1] = t[1], wdot[c + 2] = t[2], wdot[c + 3] = t[3];
+            }
+        }
+    }
+    float* sl = DOT ? slab + (int64_t)slice * E : nullptr;
+    // partial dots of the batch at positions p .. p + U - 1 (entries past `stop` are not stored)
+    auto dots = [&](const float (*v)[C], int p, int stop, int count) {
+        float mine_d = 0.f;
+#pragma unroll
+        for (int u = 0; u < count; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) d = fmaf(v[u][c], wdot[c], d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            mine_d = (sub == u) ? d : mine_d;
+        }
+        if (sub < count && p + sub < stop) sl[p + sub] = mine_d;
+    };
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
@@ -252,6 +287,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             for (int u = 0; u < U; ++u) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
+            if (DOT) dots(v, p, end, U);
 #pragma unroll
             for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
                 const float cf = __uint_as_float(pk[u].y);
@@ -266,6 +302,16 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             for (int u = 0; u < U - 1; ++u) {
                 if (p + u < end) Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C), v[u]);
             }
+            if (DOT) {
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u) {
+                    if (!(p + u < end)) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) v[u][c] = 0.f;
+                    }
+                }
+            }
+            if (DOT) dots(v, p, end, U - 1);
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
                 if (p + u < end) {
@@ -511,10 +557,11 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
 constexpr int SKEW_T = 512;
 constexpr unsigned LONG_GRID = 256;
 
-template <typename RT, bool FUSE = false>
+template <typename RT, bool FUSE = false, bool DOT = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
-                          float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr) {
+                          float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr,
+                          const float* Wdot = nullptr, float* slab = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -528,9 +575,9 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
+    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                        (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                       shadow, skew, SKEW_T);
+                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k);
     return true;
 }
 
@@ -558,6 +605,14 @@ static bool wide_eligible(int64_t D) { return D % 256 == 0 && D >= 512 && D / 25
 static size_t slab_bytes(int64_t N, int64_t k, int64_t D) {
     return wide_eligible(D) ? (size_t)(D / 256) * (size_t)N * (size_t)k * sizeof(float) : 0;
 }
+// the L2-sliced dcoeff path (fp32 rows): one partial per entry and 128-byte slice, next to the
+// slice-major copy of the rows
+static bool l2dot_eligible(int64_t N, int64_t k, int64_t D) {
+    return D % 32 == 0 && D >= 512 && (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) <= ((size_t)8 << 30);
+}
+static size_t l2dot_bytes(int64_t N, int64_t k, int64_t D) {
+    return l2dot_eligible(N, k, D) ? ((rows_sm_bytes(N, D) + 255) & ~(size_t)255) + (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) : 0;
+}
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
 static size_t long_list_bytes(int64_t N, int64_t k) {
@@ -571,9 +626,12 @@ static int* skew_word(void* workspace, int64_t N, int64_t k, int64_t D) {
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
     if (N <= 0 || k <= 0 || D <= 0) return 0;
     // packed entry list + max(slice-major copy of `rows` (no dcoeff), per-slice dot slab (dcoeff))
-    const size_t a = rows_sm_bytes(N, D), b = slab_bytes(N, k, D);
+    size_t a = rows_sm_bytes(N, D);
+    const size_t b = slab_bytes(N, k, D), c = l2dot_bytes(N, k, D);
+    a = a > b ? a : b;
+    a = a > c ? a : c;
     // + the list of long latents (at most N k / SKEW_T of them, preceded by their count)
-    return packed_bytes(N, k) + (((a > b ? a : b) + 255) & ~(size_t)255) + long_list_bytes(N, k);
+    return packed_bytes(N, k) + ((a + 255) & ~(size_t)255) + long_list_bytes(N, k);
 }
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
@@ -612,6 +670,20 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
     const bool want_wide = dot ? ((force && force[0] == 's') || (big && N * k >= 4 * M))
                                : ((force && force[0] == 'w') || (big && N * k >= 64 * M));
+    // dcoeff at training sizes with fp32 rows: the L2-sliced kernel with per-slice dot partials
+    // (the N x 128 B slice of the rows stays in L2: twice the Infinity Cache's rate);
+    // SPHIP_WGRAD=wide keeps the wide kernel (A/B), =l2 forces this one
+    if (dot && rows_dtype == SPHIP_F32 && l2dot_eligible(N, k, D) && D / 32 <= 65535 &&
+        ((force && force[0] == 'l') || (!force && big && N * k >= 4 * M && N * 128 <= (3ll << 20)))) {
+        float* slab = (float*)((char*)rows_sm + ((rows_sm_bytes(N, D) + 255) & ~(size_t)255));
+        if (launch_sliced<float, false, true>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M,
+                                              (int)D, s, 0.f, nullptr, nullptr, W, slab)) {
+            SPHIP_CHECK_LAUNCH("segmented_weight_grad(l2 dot)");
+            hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
+            SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
+            return SPHIP_OK;
+        }
+    }
     if (wide_eligible(D) && !(force && force[0] == 'f') && want_wide) {
         float* slab = (float*)rows_sm;
         const FastDiv kd = make_fastdiv((unsigned)k);
