@@ -548,7 +548,15 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= seg_begin[M]) return;
     float t = 0.f;
-    for (int sidx = 0; sidx < num_slices; ++sidx) t += slab[(int64_t)sidx * E + p];
+    int sidx = 0;
+    for (; sidx + 16 <= num_slices; sidx += 16) {       // 16 loads in flight, summed in slice order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(slab + (int64_t)(sidx + u) * E + p);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    for (; sidx < num_slices; ++sidx) t += slab[(int64_t)sidx * E + p];
     dcoeff[packed[p].x] = t;
 }
 
