@@ -408,10 +408,11 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
                                                              const float* __restrict__ row_shift, FastDiv kdiv,
                                                              int64_t E, int M, int D,
                                                              const int* __restrict__ skew = nullptr, int skew_T = 0,
-                                                             float lr = 0.f, bf16_t* __restrict__ shadow = nullptr) {
+                                                             float lr = 0.f, bf16_t* __restrict__ shadow = nullptr,
+                                                             int slice0 = 0) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slice = blockIdx.y;
+    const int slice = blockIdx.y + slice0;
     if (LIST) {
         // launched next to the L2-sliced kernel with a small fixed grid: the waves walk the list
         // of long latents (skew[0] = their number, skew[1..] = the latents; usually empty)
@@ -560,6 +561,37 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
     dcoeff[packed[p].x] = t;
 }
 
+// The same sum when latents with more than T entries took the wide kernel (nB slices of 256
+// columns in slabB) and all others the L2-sliced one (nA slices of 32 columns in slabA): the
+// latent of position p is found by bisection of seg_begin.
+__global__ __launch_bounds__(256) void seg_dcoeff_mixed_kernel(const uint2* __restrict__ packed,
+                                                               const float* __restrict__ slabA, int nA,
+                                                               const float* __restrict__ slabB, int nB, int64_t E,
+                                                               const int* __restrict__ seg_begin, int M, int T,
+                                                               float* __restrict__ dcoeff) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= seg_begin[M]) return;
+    int lo = 0, hi = M;                       // invariant: seg_begin[lo] <= p < seg_begin[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_begin[mid] <= p) lo = mid; else hi = mid;
+    }
+    const bool is_long = seg_begin[lo + 1] - seg_begin[lo] > T;
+    const float* slab = is_long ? slabB : slabA;
+    const int n = is_long ? nB : nA;
+    float t = 0.f;
+    int sidx = 0;
+    for (; sidx + 16 <= n; sidx += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(slab + (int64_t)(sidx + u) * E + p);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    for (; sidx < n; ++sidx) t += slab[(int64_t)sidx * E + p];
+    dcoeff[packed[p].x] = t;
+}
+
 // segments longer than this go from the L2-sliced kernel to the wide kernel, whose waves (a small
 // fixed grid of LONG_GRID workgroups per column slice) walk the list of such latents
 constexpr int SKEW_T = 512;
@@ -619,7 +651,10 @@ static bool l2dot_eligible(int64_t N, int64_t k, int64_t D) {
     return D % 32 == 0 && D >= 512 && (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) <= ((size_t)8 << 30);
 }
 static size_t l2dot_bytes(int64_t N, int64_t k, int64_t D) {
-    return l2dot_eligible(N, k, D) ? ((rows_sm_bytes(N, D) + 255) & ~(size_t)255) + (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) : 0;
+    // slice-major rows + 128-byte-slice partials + the wide kernel's partials for long latents
+    return l2dot_eligible(N, k, D) ? ((rows_sm_bytes(N, D) + 255) & ~(size_t)255) +
+                                         (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) + slab_bytes(N, k, D)
+                                   : 0;
 }
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
@@ -684,10 +719,28 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     if (dot && rows_dtype == SPHIP_F32 && l2dot_eligible(N, k, D) && D / 32 <= 65535 &&
         ((force && force[0] == 'l') || (!force && big && N * k >= 4 * M && N * 128 <= (3ll << 20)))) {
         float* slab = (float*)((char*)rows_sm + ((rows_sm_bytes(N, D) + 255) & ~(size_t)255));
+        float* slab_long = slab + (size_t)(D / 32) * (size_t)E;
+        // latents with more than SKEW_T entries (dense latents: a workgroup of the sliced kernel
+        // lives as long as its longest segment) are listed on the device and left to the
+        // wave-per-latent wide kernel, launched next to the sliced one with a small fixed grid
+        int* skew = wide_eligible(D) ? skew_word(workspace, N, k, D) : nullptr;
+        if (skew != nullptr) {
+            SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
+            hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
+        }
         if (launch_sliced<float, false, true>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M,
-                                              (int)D, s, 0.f, nullptr, nullptr, W, slab)) {
+                                              (int)D, s, 0.f, nullptr, skew, W, slab)) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(l2 dot)");
-            hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
+            if (skew != nullptr) {
+                // (four column slices per launch, to keep the list's working set inside the
+                // Infinity Cache, measured slower: 32 against 26 ms on the collapsed 262144-latent
+                // transcoder run; the list's waves are latency-bound, not bandwidth-bound)
+                dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
+                hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, true, false, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab_long, row_shift, make_fastdiv((unsigned)k), E, (int)M, (int)D, skew, SKEW_T);
+                hipLaunchKernelGGL(seg_dcoeff_mixed_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, (int)(D / 32), slab_long, (int)(D / 256), E, seg_begin, (int)M, SKEW_T, dcoeff);
+            } else {
+                hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
+            }
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
             return SPHIP_OK;
         }

@@ -680,3 +680,32 @@ def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, ske
     ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused, lr, sh_fused, row_shift=shift)
     assert torch.equal(sep, fused) and torch.equal(sh_sep.view(torch.int16), sh_fused.view(torch.int16))
     assert torch.equal(ops.segment_coeff_sums(seg, coeff), gb)
+
+
+@pytest.mark.parametrize("skewed", [False, True])
+def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
+    """W_dec gradient + d top_acts through the L2-sliced kernel with per-slice dot partials
+    (SPHIP_WGRAD=l2; long segments go to the wide kernel over the device-side list, and the sum of
+    the partials picks the right slab per entry): gW bit for bit the full-row kernel's, the dots
+    equal up to summation order."""
+    from sparsify_amd import ops
+    torch.manual_seed(11)
+    N, D, M, k = 4096, 1024, 4096, 32
+    idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
+    if skewed:
+        idx[:, :2] = torch.tensor([5, 4090])             # two latents fire on every token
+        idx[::3, 2] = 17                                  # one on every third (1366 entries > 512)
+    idx, coeff = dev(idx), dev(torch.randn(N, k).to(torch.bfloat16))
+    rows, W = dev(torch.randn(N, D)), dev(torch.randn(M, D))
+    seg = ops.build_latent_segments(idx, M)
+    monkeypatch.setenv("SPHIP_WGRAD", "l2")
+    gW, gb, dc = ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True)
+    gW2, _, dc2 = ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True)
+    assert torch.equal(gW, gW2) and torch.equal(dc, dc2)                      # deterministic
+    monkeypatch.setenv("SPHIP_WGRAD", "full")
+    gW_f, gb_f, dc_f = ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True)
+    assert torch.equal(gW, gW_f) and torch.equal(gb, gb_f)
+    ref = (rows[:, None, :] * W[idx]).sum(-1) if N * k * D <= (1 << 28) else None
+    torch.testing.assert_close(dc, dc_f, rtol=1e-4, atol=1e-3)
+    if ref is not None:
+        torch.testing.assert_close(dc, ref, rtol=1e-4, atol=1e-3)
