@@ -79,7 +79,9 @@ def measured_traffic(kernel_prefix: str):
     runs of their own, FETCH_SIZE doubled for gfx950). Counters cannot be read inside a timed
     run, so this is the profile's number for the same command, or None if there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])      # r01_v9 < r01_v10
     if not files:
         return None, None
     prof = json.load(open(files[-1]))
