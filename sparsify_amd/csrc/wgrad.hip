@@ -874,22 +874,28 @@ extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const i
 namespace sphip {
 __global__ __launch_bounds__(256) void slice_major_tiled_kernel(const float* __restrict__ src, uint4* __restrict__ dst,
                                                                 int64_t R, int D, int num_slices) {
-    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int sub = threadIdx.x & 7;
-    if (row >= R) return;
-    // the workgroup walks its 32 rows from end to end, 1 KiB of each at a time
-    // (workgroups start at different slice groups: at any time the stores of the chip then go to
-    // many slices, not all to the same one 128 * R bytes apart)
-    const int groups = (num_slices + 7) / 8;
-    for (int gi = 0; gi < groups; ++gi) {
-        const int s0 = ((gi + (int)(blockIdx.x % (unsigned)groups)) % groups) * 8;
-        uint4 v[8];
+    // 32 rows x 8 slices (1 KiB of each row) per step through LDS: a wave reads 1 KiB of one row
+    // and writes 1 KiB of one slice (8 rows x 128 B), both contiguous
+    constexpr int ROWCH = 65;                               // 16-byte chunks per LDS row (64 + 1 pad)
+    __shared__ uint4 tile[32 * ROWCH];
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int t = threadIdx.x;
+    for (int s0 = 0; s0 < num_slices; s0 += 8) {
+        const int chunks = min(8, num_slices - s0) * 8;    // valid chunks of the 1 KiB window
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (s0 + u < num_slices) v[u] = *reinterpret_cast<const uint4*>(src + row * D + (s0 + u) * 32 + sub * 4);
+        for (int r = 0; r < 8; ++r) {
+            const int row = r * 4 + (t >> 6), c = t & 63;
+            if (row0 + row < R && c < chunks)
+                tile[row * ROWCH + c] = *reinterpret_cast<const uint4*>(src + (row0 + row) * D + s0 * 32 + c * 4);
+        }
+        __syncthreads();
+        const int row = t >> 3, sub = t & 7;
+        if (row0 + row < R) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (s0 + u < num_slices) dst[((int64_t)(s0 + u) * R + row) * 8 + sub] = v[u];
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < num_slices) dst[((int64_t)(s0 + u) * R + row0 + row) * 8 + sub] = tile[row * ROWCH + u * 8 + sub];
+        }
+        __syncthreads();
     }
 }
 }  // namespace sphip

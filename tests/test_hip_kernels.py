@@ -709,3 +709,14 @@ def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
     torch.testing.assert_close(dc, dc_f, rtol=1e-4, atol=1e-3)
     if ref is not None:
         torch.testing.assert_close(dc, ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("R,D", [(1000, 96), (33, 4096), (4099, 288), (64, 32)])
+def test_slice_major_copy_ragged(device, R, D):
+    """sphip_slice_major_f32 on row counts that are not whole 32-row tiles and slice counts that are
+    not whole groups of 8."""
+    from sparsify_amd import ops
+    torch.manual_seed(R + D)
+    t = dev(torch.randn(R, D))
+    sm = ops.slice_major_copy(t)
+    assert torch.equal(sm, t.view(R, D // 32, 32).transpose(0, 1))
