@@ -2,6 +2,12 @@ import os
 import sys
 from pathlib import Path
 
+# The CPU tests are many tiny torch ops; on a box whose vCPUs are shared, 8 OpenMP threads spin on
+# each other (measured here: 24 s against 1.2 s on one thread for 200 small steps). Two threads
+# unless the environment says otherwise (the GPU box sets OMP_NUM_THREADS itself); set before torch
+# loads so that the world-size-2 gloo subprocesses inherit it.
+os.environ.setdefault("OMP_NUM_THREADS", "2")
+
 import numpy as np
 import pytest
 import torch
