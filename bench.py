@@ -37,7 +37,11 @@ WORKLOADS = {
     "llama3-8b-transcoder d_in=4096 M=262144 k=192": dict(d_in=4096, num_latents=262144, k=192, transcode=True),
 }
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s
+# Ceilings of the memory levels the byte-bound kernels are served from (MI355X_MICROARCH.md, "Indexed
+# rows: gather into LDS" and "HBM"): random rows out of the XCDs' L2s 16.8-18.8 TB/s measured chip-wide
+# (the upper end is used, so a fraction never flatters), out of the Infinity Cache 7.4-8.6 TB/s, HBM
+# 8.0 TB/s spec (6.3 TB/s is what a streaming copy achieves).
+PEAK_GBS = {"L2": 18800.0, "MALL": 8600.0, "HBM": 8000.0}
 
 
 def cpu_baseline(w: dict, tokens: int, budget_s: float = 25.0) -> dict:
@@ -73,26 +77,57 @@ def cpu_baseline(w: dict, tokens: int, budget_s: float = 25.0) -> dict:
                       f"the reference's (N*k,D) fp32 temporary forbids the GPU batch size on CPU"}
 
 
-def measured_traffic(kernel_prefix: str):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r*_pmc_summary.json, made by benchmarks/profile.sh: FETCH_SIZE and WRITE_SIZE in
-    runs of their own, FETCH_SIZE doubled for gfx950). Counters cannot be read inside a timed
-    run, so this is the profile's number for the same command, or None if there is none."""
+def newest_profile():
+    """The newest committed counter summary (profiles/r*_pmc_summary.json, made on the GPU box by
+    benchmarks/profile.sh from this command: kernel-trace stats + FETCH_SIZE, WRITE_SIZE, TCC hit/miss
+    and SQ/GRBM passes in runs of their own, FETCH_SIZE doubled for gfx950). Counters cannot be read
+    inside a timed run, so the bench line quotes the profile's numbers next to its own live timings."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")),
                    key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])      # r01_v9 < r01_v10
     if not files:
-        return None, None
-    prof = json.load(open(files[-1]))
+        return None, {}
+    return os.path.basename(files[-1]), json.load(open(files[-1]))
+
+
+def profiled(prof: dict, prefixes) -> dict | None:
+    """Per-step totals over the profile's kernels whose names start with one of `prefixes`:
+    duration, HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE), launches per step."""
+    steps = prof.get("_steps", 6)            # profile.sh: 2 warm-up + 4 timed steps, all traced
+    ms = by = n = 0.0
     for name, d in prof.items():
-        if name.startswith(kernel_prefix) and "fetch_bytes_per_launch" in d and "write_bytes_per_launch" in d:
-            util = None
-            if d.get("SQ_VALU_MFMA_BUSY_CYCLES") and d.get("GRBM_GUI_ACTIVE"):
-                # busy cycles are summed over 256 CUs x 4 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
-                util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)
-            return d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"], util
-    return None, None
+        if isinstance(d, dict) and any(name.startswith(p) for p in prefixes) and "avg_us" in d:
+            calls = d.get("calls", 0) / steps
+            ms += d["avg_us"] * 1e-3 * calls
+            by += (d.get("fetch_bytes_per_launch", 0.0) + d.get("write_bytes_per_launch", 0.0)) * calls
+            n += calls
+    return {"ms": ms, "counter_bytes": by, "launches": n} if n else None
+
+
+def kernel_reports(N: int, D: int, M: int, k: int):
+    """The byte-bound entry points of the step: (timer name, what, level that serves the bulk of
+    its bytes, algorithmic bytes per step (SURVEY.md 8d figures x the units one launch processes),
+    the kernels it launches as named in the rocprof summaries)."""
+    G = 1 << 30
+    return [
+        ("sphip_gather_rows_weighted", "decode: sum of k W_dec rows per token + b_dec (L2-resident gather; "
+         "includes bucketing and the slice-major copy of W_dec)", "L2", N * (k * D * 4 + D * 4),
+         ["sphip::gather_l2_kernel", "sphip::bucket", "sphip::slice_major"]),
+        ("sphip_segmented_weight_grad", "W_dec.grad (dense, all M rows) + d top_acts: N k rows of dL/dy gathered, "
+         "W_dec read, gradient written", "L2", N * k * D * 4 + 2 * (M * D * 4),
+         ["sphip::seg_wgrad_sliced_kernel<float", "sphip::seg_dcoeff", "sphip::slice_major_kernel", "sphip::seg_pack",
+          "sphip::seg_long", "sphip::seg_wgrad_wide"]),
+        ("sphip_segmented_weight_grad_signsgd", "encoder.weight gradient fused with its SignSGD step: N k bf16 rows "
+         "gathered, parameter read + written, bf16 shadow written", "L2", N * k * D * 2 + M * D * (4 + 4 + 2),
+         ["sphip::seg_wgrad_sliced_kernel<unsigned short"]),
+        ("sphip_topk", "row top-k from the block maxima: the maxima + one 256-B block per selected latent",
+         "HBM", N * (M // 128) * 2 + N * k * 256, ["sphip::topk_kernel"]),
+        ("sphip_decoder_project_signsgd", "decoder step tail: projected gradient + sign step + re-normalisation, "
+         "W_dec and its gradient read, W_dec written", "HBM", 3 * M * D * 4, ["sphip::decoder_row_resident_kernel"]),
+        ("sphip_vec_mat", "b_dec's encoder-side gradient gb^T W_enc: one pass over encoder.weight", "HBM", M * D * 4,
+         ["sphip::col_partial_kernel<float"]),
+    ]
 
 
 def main():
@@ -104,6 +139,7 @@ def main():
     ap.add_argument("--workload", default="llama3-8b-layer d_in=4096 M=131072 k=192", choices=list(WORKLOADS))
     ap.add_argument("--cpu-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auxk", action="store_true", help="skip the second (AuxK) run of the headline workload")
     ap.add_argument("--fp32", action="store_true", help="fp32 activations / no autocast (not the headline)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -188,20 +224,56 @@ def main():
         parallel.all_reduce_(t, "max")
     elapsed = float(t.item())
 
+    headline = args.workload.startswith("llama3-8b-layer") and N == 16384 and not args.fp32 and not shard
+    auxk_ms = None
+    if headline and world == 1 and not args.no_auxk and args.optimizer == "signsgd":
+        del trainer, sae, batches
+        torch.cuda.empty_cache()
+        auxk_ms = auxk_run(N, D, M, k, device)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         # one launch per step, or one per latent block when the forward follows an overlapped
         # gradient exchange (N > 1): the roofline figure is per step either way
         gemm_ms = sum(kern[n]["total_ms"] for n in ("sphip_encoder_preacts", "sphip_encoder_preacts_block")
                       if n in kern) / args.steps
-        gemm = {"mean_ms": gemm_ms}
         flops = 2.0 * N * D * M / (world if shard else 1)        # algorithmic FLOP per step and rank
-        tflops = flops / (gemm["mean_ms"] * 1e-3) / 1e12
-        dec = kern["sphip_gather_rows_weighted"]
-        wg = kern["sphip_segmented_weight_grad"]
-        gather_bytes = N * (k * D * 4 + D * 4)                    # decode fwd per token
-        headline = args.workload.startswith("llama3-8b-layer") and N == 16384 and not args.fp32
-        traffic, mfma_util = measured_traffic("sphip::encoder_gemm256_kernel<true") if headline else (None, None)
+        tflops = flops / (gemm_ms * 1e-3) / 1e12
+        prof_name, prof = newest_profile() if headline else (None, {})
+        roof = {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                "kernel": "encoder_gemm256_kernel (sphip_encoder_preacts)", "ms": gemm_ms,
+                "how": "achieved = 2*N*D*M FLOP / the kernel's mean duration in THIS run (HIP events on the launching "
+                       "stream); `profiled` = the same from the committed rocprofv3 run of this command, on the box "
+                       "and at the clock named there (boxes of the pool differ by several per cent)"}
+        g = prof.get(next((n for n in prof if n.startswith("sphip::encoder_gemm256_kernel<true")), ""), None)
+        if g:
+            pt = flops / (g["avg_us"] * 1e-6) / 1e12
+            roof["traffic"] = g.get("fetch_bytes_per_launch", 0.0) + g.get("write_bytes_per_launch", 0.0)
+            roof["profiled"] = {
+                "file": f"profiles/{prof_name}", "ms": g["avg_us"] * 1e-3, "achieved": pt,
+                "frac": pt / MFMA_BF16_DENSE_PEAK_TFLOPS, "effective_clock_GHz": g.get("effective_clock_GHz"),
+                # busy cycles are summed over 256 CUs x 4 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+                "mfma_busy_frac_of_cycles": (g["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (g["GRBM_GUI_ACTIVE"] / 8)
+                                             if g.get("SQ_VALU_MFMA_BUSY_CYCLES") and g.get("GRBM_GUI_ACTIVE") else None),
+                "l2_hit_rate": g.get("l2_hit_rate"),
+                "traffic_note": "traffic = HBM-side bytes per launch, FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes",
+            }
+        byte_kernels = None
+        if not shard:
+            # per-rank partial work in shard mode: the one-GPU byte counts do not apply
+            byte_kernels = {}
+            for name, what, level, alg_bytes, kernel_names in kernel_reports(N, D, M, k):
+                if name not in kern:
+                    continue
+                t_ms = kern[name]["total_ms"] / args.steps
+                ach = alg_bytes / (t_ms * 1e-3) / 1e9
+                entry = {"what": what, "bound": level, "algorithmic_bytes": alg_bytes, "ms": t_ms, "achieved_GBs": ach,
+                         "peak_GBs": PEAK_GBS[level], "frac": ach / PEAK_GBS[level]}
+                pk = profiled(prof, kernel_names) if prof else None
+                if pk:
+                    entry["profiled"] = {"ms": pk["ms"], "counter_bytes": pk["counter_bytes"], "launches": pk["launches"]}
+                byte_kernels[name] = entry
         out = {
             "metric": "SAE train tokens/sec at d=4096, M=131072, k=192 (1-8 GPUs); MFMA util %",
             "value": N * (1 if shard else world) * args.steps / elapsed,
@@ -217,21 +289,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": args.optimizer,
                        "params": "fp32", "parallelism": f"latent-shard{world}" if shard else f"dp{world}", "mean_fvu": fvu},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) from the committed "
-                                         "rocprofv3 --pmc passes of this command, profiles/r*_pmc_summary.json",
-                         "mfma_util_pct_profiled": None if mfma_util is None else 100.0 * mfma_util,
-                         "kernel": "encoder_gemm256_kernel (sphip_encoder_preacts)", "ms": gemm["mean_ms"]},
+            "roofline": roof,
             "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in kern.items()},
-            # per-rank partial work in shard mode: the one-GPU byte counts do not apply
-            "hbm_kernels": None if shard else {
-                "decode_gather_GBs": gather_bytes / (dec["total_ms"] / dec["calls"] * 1e-3) / 1e9,
-                "segmented_wgrad_GBs": 2 * N * k * D * 4 / (wg["total_ms"] / args.steps * 1e-3) / 1e9,
-                # M*2 B read per token (the kernel itself reads ~1/4 of that)
-                "topk_GBs": N * M * 2 / (kern["sphip_topk"]["total_ms"] / args.steps * 1e-3) / 1e9,
-                "peak_GBs": HBM_PEAK_GBS,
-            },
+            "byte_bound_kernels": byte_kernels,
+            "byte_bound_note": "achieved = algorithmic bytes (SURVEY.md 8d) / live HIP-event time, against the measured "
+                               "ceiling of the level that serves the bulk of them (MI355X_MICROARCH.md: random rows out "
+                               "of L2 16.8-18.8 TB/s, Infinity Cache 7.4-8.6 TB/s, HBM 8.0 TB/s spec / 6.3 achievable); "
+                               "profiled.counter_bytes = HBM-side FETCH_SIZE x2 + WRITE_SIZE of the same kernels in "
+                               f"profiles/{prof_name}",
+            "extra": {"auxk_ms_per_step": auxk_ms,
+                      "auxk_note": "second run (SURVEY.md 8d): auxk_alpha = 1/32, 10 % of the latents dead, k_aux = 2048"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_tokens)
@@ -239,6 +306,28 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def auxk_run(N, D, M, k, device, steps: int = 4, warm: int = 2) -> float:
+    """The headline step with the AuxK term (sparse_coder.py:230-251): auxk_alpha = 1/32, about 10 %
+    of the latents held dead, k_aux = d_in / 2. Returns ms per step."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.trainer import SyntheticActivations, Trainer
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h"], auxk_alpha=1 / 32,
+                      dead_feature_threshold=10**6, save_every=10**9, wandb_log_frequency=10**9, save_dir="")
+    src = SyntheticActivations(["h"], D, N, steps + warm, device=device)
+    tr = Trainer(cfg, src, device=device)
+    dead = torch.rand(M, device=device, generator=torch.Generator(device=device).manual_seed(0)) < 0.10
+    batches = [src.batch(s) for s in range(steps + warm)]
+    t0 = 0.0
+    for s in range(steps + warm):
+        if s == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        tr.num_tokens_since_fired["h"][dead] = 10**7          # these stay dead unless they fire
+        tr.train_micro_batch(batches[s])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def _fp32_forward(fwd, self, *a, **kw):

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-ARGS="bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+ARGS="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-auxk"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1 || { echo "stats pass failed"; exit 1; }
 echo "stats pass done"
 i=0

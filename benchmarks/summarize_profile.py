@@ -41,4 +41,5 @@ for k, d in out.items():
     if "GRBM_GUI_ACTIVE" in d and "avg_us" in d:
         d["effective_clock_GHz"] = d["GRBM_GUI_ACTIVE"] / 8 / (d["avg_us"] * 1e-6) / 1e9
 top = dict(sorted(out.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("calls", 0))[:24])
+top["_steps"] = int(sys.argv[2]) if len(sys.argv) > 2 else 6      # steps traced (warm-up included): calls / _steps = launches per step
 print(json.dumps(top, indent=1))

@@ -48,7 +48,7 @@ class DeadLatentDecode(torch.autograd.Function):
         N = indices.shape[0]
         M, D = W_dec.shape
         Kd = -(-num_dead // 64) * 64
-        A, At = ops.dead_scatter_acts(indices, acts.contiguous(), slot_of, Kd)
+        A, At = ops.dead_scatter_acts(indices, acts.contiguous(), slot_of, Kd, num_valid=num_dead)
         w_parts = ops.split_bf16_transposed(W_dec.detach(), dead_list, num_dead, Kd)      # 3 x (D, Kd)
         out = ops.broadcast_rows(b_dec.detach(), N)
         for p in range(3):

@@ -221,7 +221,11 @@ class ModelTrainer(Trainer):
                 n_step = int(mask.sum()) * (dist.get_world_size() if dist.is_initialized() else 1)
             self.num_tokens_in_step += n_step
             self.step_tail()
+        from . import parallel
+        parallel.wait_for_updates()
         self.save()
+        if cfg.save_best:                                            # trainer.py:592-594
+            self.save_best(self._avg_losses())
 
 
 def set_submodule(model: nn.Module, submodule_path: str, new_submodule: nn.Module):

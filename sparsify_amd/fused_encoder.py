@@ -29,7 +29,39 @@ class EncoderOutput(NamedTuple):
     """Activations before the top-k selection."""
 
 
+import weakref
+
+# address -> (weak reference to the owning tensor, (version, shape), bf16 buffer). The weak
+# reference pins an entry to the tensor it was made for: the caching allocator hands a freed
+# block to the next same-sized request, so a later parameter can live at the same address with
+# the same shape and version counter (every coder loaded from disk sits at version 2). An entry
+# whose owner has died is dropped, together with its (M, D) bf16 buffer.
 _shadows: dict[int, tuple] = {}
+
+
+def _shadow_entry(t: Tensor):
+    hit = _shadows.get(t.data_ptr())
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if owner is None or owner.data_ptr() != t.data_ptr() or owner.shape != t.shape or owner._version != t._version:
+        # the owner is gone, or `t` is another tensor at a recycled address (an alias of the owner
+        # -- a view, .detach() -- shares its version counter and passes)
+        if owner is None:
+            _shadows.pop(t.data_ptr(), None)
+        return None
+    return hit
+
+
+def _store_shadow(t: Tensor, shadow: Tensor) -> None:
+    key = t.data_ptr()
+
+    def _drop(ref, key=key):
+        hit = _shadows.get(key)
+        if hit is not None and hit[0] is ref:
+            del _shadows[key]
+
+    _shadows[key] = (weakref.ref(t, _drop), (t._version, tuple(t.shape)), shadow)
 
 
 def bf16_shadow(t: Tensor) -> Tensor:
@@ -37,32 +69,38 @@ def bf16_shadow(t: Tensor) -> Tensor:
 
     Autocast re-casts encoder.weight (2 GiB read at the headline shape) on every call
     (sparse_coder.py:205-209 + fused_encoder.py:29); the values are identical, we just keep
-    them until the optimizer bumps the parameter's version."""
+    them until the optimizer bumps the parameter's version. Pass the parameter itself (not a
+    temporary alias): the entry lives as long as the tensor object it was made for."""
     if t.dtype == torch.bfloat16:
         return t
-    key = t.data_ptr()
-    hit = _shadows.get(key)
-    if hit is not None and hit[0] == (t._version, tuple(t.shape)):
-        return hit[1]
-    buf = hit[1] if hit is not None and hit[1].shape == t.shape else None
+    hit = _shadow_entry(t)
+    if hit is not None and hit[1] == (t._version, tuple(t.shape)):
+        return hit[2]
+    buf = hit[2] if hit is not None and hit[2].shape == t.shape else None
     sh = ops.cast_bf16(t.detach().contiguous(), buf)
-    _shadows[key] = ((t._version, tuple(t.shape)), sh)
+    _store_shadow(t, sh)
     return sh
 
 
 def register_bf16_shadow(t: Tensor, shadow: Tensor) -> None:
     """Tell the cache that `shadow` already equals bf16(t) (written by a fused update)."""
-    _shadows[t.data_ptr()] = ((t._version, tuple(t.shape)), shadow)
+    _store_shadow(t, shadow)
 
 
 def peek_bf16_shadow(t: Tensor) -> Tensor | None:
+    """The buffer holding (a possibly stale) bf16(t), for an update kernel to refresh in place."""
     hit = _shadows.get(t.data_ptr())
-    return hit[1] if hit is not None and hit[1].shape == t.shape else None
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if owner is None or owner.data_ptr() != t.data_ptr() or owner.shape != t.shape:
+        return None
+    return hit[2]
 
 
 def shadow_is_current(t: Tensor) -> bool:
-    hit = _shadows.get(t.data_ptr())
-    return hit is not None and hit[0] == (t._version, tuple(t.shape))
+    hit = _shadow_entry(t)
+    return hit is not None and hit[1] == (t._version, tuple(t.shape))
 
 
 # Optimizer-in-backward for the encoder matrix (sign_sgd.SignSGD.fuse_encoder_update): the
@@ -74,7 +112,6 @@ _inplace_signsgd: dict[int, tuple] = {}
 
 
 def register_inplace_signsgd(param: Tensor, lr_of) -> None:
-    import weakref
     _inplace_signsgd[param.data_ptr()] = (weakref.ref(param), lr_of)
 
 

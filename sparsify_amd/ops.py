@@ -104,8 +104,10 @@ def center_cast(x: Tensor, b_dec: Tensor | None, want_f32: bool, want_bf16: bool
         _req(b_dec, "b_dec", torch.float32, 1)
     of = torch.empty(N, D, dtype=torch.float32, device=x.device) if want_f32 else None
     ob = torch.empty(N, D, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _ev = timer.start("sphip_center_cast", x)
     check(_lib.load().sphip_center_cast(x.data_ptr(), _dt(x), _ptr(b_dec), _ptr(of), _ptr(ob), N, D, _stream(x)),
           "sphip_center_cast")
+    timer.stop(_ev, x)
     return of, ob
 
 
@@ -214,19 +216,30 @@ _slice_major: dict[int, tuple] = {}
 
 def slice_major_copy(table: Tensor) -> Tensor:
     """[D/32][M][32] copy of a (M, D) fp32 table (sphip_slice_major_f32), refreshed only when the
-    table's version changed -- the optimizer steps bump it, like the bf16 shadow of encoder.weight."""
+    table's version changed -- the optimizer steps bump it, like the bf16 shadow of encoder.weight.
+    An entry is pinned to the tensor it was made for by a weak reference (a later parameter at a
+    recycled address with the same shape and version must not hit it) and dies with that tensor."""
+    import weakref
     key = table.data_ptr()
     hit = _slice_major.get(key)
+    if hit is not None:
+        owner = hit[0]()
+        if owner is None or owner.data_ptr() != key or owner.shape != table.shape or owner._version != table._version:
+            hit = None
     state = (table._version, tuple(table.shape))
-    if hit is not None and hit[0] == state:
-        return hit[1]
+    if hit is not None and hit[1] == state:
+        return hit[2]
     M, D = table.shape
-    buf = hit[1] if hit is not None and hit[1].numel() == table.numel() else torch.empty(D // 32, M, 32, dtype=torch.float32,
+    buf = hit[2] if hit is not None and hit[2].numel() == table.numel() else torch.empty(D // 32, M, 32, dtype=torch.float32,
                                                                                         device=table.device)
     check(_lib.load().sphip_slice_major_f32(table.data_ptr(), buf.data_ptr(), M, D, _stream(table)), "sphip_slice_major_f32")
-    if len(_slice_major) > 8:
-        _slice_major.clear()
-    _slice_major[key] = (state, buf)
+
+    def _drop(ref, key=key):
+        cur = _slice_major.get(key)
+        if cur is not None and cur[0] is ref:
+            del _slice_major[key]
+
+    _slice_major[key] = (weakref.ref(table, _drop), state, buf)
     return buf
 
 
@@ -360,8 +373,10 @@ def segment_coeff_sums(seg: LatentSegments, coeff: Tensor) -> Tensor:
     if tuple(coeff.shape) != (seg.N, seg.k):
         raise ValueError("segment_coeff_sums: shape mismatch")
     out = torch.empty(seg.M, dtype=torch.float32, device=coeff.device)
+    _ev = timer.start("sphip_segment_coeff_sums", coeff)
     check(_lib.load().sphip_segment_coeff_sums(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff),
                                               seg.M, out.data_ptr(), _stream(coeff)), "sphip_segment_coeff_sums")
+    timer.stop(_ev, coeff)
     return out
 
 
@@ -386,7 +401,7 @@ def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Ten
             raise ValueError("segmented_weight_grad_signsgd: shadow shape mismatch")
     lib = _lib.load()
     ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
-    _ev = timer.start("sphip_segmented_weight_grad", rows)
+    _ev = timer.start("sphip_segmented_weight_grad_signsgd", rows)
     check(lib.sphip_segmented_weight_grad_signsgd(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff),
                                                   rows.data_ptr(), _dt(rows), _ptr(row_shift), N, k, M, D, param.data_ptr(),
                                                   float(lr), _ptr(bf16_shadow), ws.data_ptr(), ws.numel(), _stream(rows)),
@@ -405,8 +420,10 @@ def total_variance(y: Tensor) -> Tensor:
     N, D = y.shape
     tv = torch.empty(1, dtype=torch.float32, device=y.device)
     ws = _red_ws(y, N, D)
+    _ev = timer.start("sphip_total_variance", y)
     check(_lib.load().sphip_total_variance(y.data_ptr(), _dt(y), N, D, tv.data_ptr(), ws.data_ptr(), ws.numel(),
                                           _stream(y)), "sphip_total_variance")
+    timer.stop(_ev, y)
     return tv
 
 
@@ -420,8 +437,10 @@ def residual_sumsq(a: Tensor, b: Tensor, want_residual: bool = True):
     e = torch.empty(N, D, dtype=torch.float32, device=a.device) if want_residual else None
     sq = torch.empty(1, dtype=torch.float32, device=a.device)
     ws = _red_ws(a, N, D)
+    _ev = timer.start("sphip_residual_sumsq", a)
     check(_lib.load().sphip_residual_sumsq(a.data_ptr(), _dt(a), b.data_ptr(), _ptr(e), sq.data_ptr(), N, D,
                                           ws.data_ptr(), ws.numel(), _stream(a)), "sphip_residual_sumsq")
+    timer.stop(_ev, a)
     return e, sq
 
 
@@ -429,8 +448,10 @@ def scale_by_ratio(src: Tensor, alpha: float, num: Tensor | None, den: Tensor | 
     _req(src, "in", torch.float32)
     if out is None:
         out = torch.empty_like(src)
+    _ev = timer.start("sphip_scale_by_ratio", src)
     check(_lib.load().sphip_scale_by_ratio(src.data_ptr(), out.data_ptr(), src.numel(), float(alpha), _ptr(num),
                                           _ptr(den), _stream(src)), "sphip_scale_by_ratio")
+    timer.stop(_ev, src)
     return out
 
 
@@ -439,8 +460,10 @@ def colsum(a: Tensor, scale: float = 1.0) -> Tensor:
     N, D = a.shape
     out = torch.empty(D, dtype=torch.float32, device=a.device)
     ws = _red_ws(a, N, D)
+    _ev = timer.start("sphip_colsum", a)
     check(_lib.load().sphip_colsum(a.data_ptr(), _dt(a), N, D, float(scale), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                   _stream(a)), "sphip_colsum")
+    timer.stop(_ev, a)
     return out
 
 
@@ -450,15 +473,19 @@ def vec_mat(v: Tensor, W: Tensor, scale: float = 1.0) -> Tensor:
     M, D = W.shape
     out = torch.empty(D, dtype=torch.float32, device=W.device)
     ws = _red_ws(W, M, D)
+    _ev = timer.start("sphip_vec_mat", W)
     check(_lib.load().sphip_vec_mat(v.data_ptr(), W.data_ptr(), M, D, float(scale), out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _stream(W)), "sphip_vec_mat")
+    timer.stop(_ev, W)
     return out
 
 
 # ------------------------------------------------------------------ dense updates
 def unit_norm_rows_(W: Tensor) -> Tensor:
     _req(W, "W_dec", torch.float32, 2)
+    _ev = timer.start("sphip_unit_norm_rows", W)
     check(_lib.load().sphip_unit_norm_rows(W.data_ptr(), W.shape[0], W.shape[1], _stream(W)), "sphip_unit_norm_rows")
+    timer.stop(_ev, W)
     return W
 
 
@@ -477,8 +504,10 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
         raise ValueError("signsgd: grad shape mismatch")
     if bf16_shadow is not None:
         _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    _ev = timer.start("sphip_signsgd_step", p)
     check(_lib.load().sphip_signsgd_step(p.data_ptr(), g.data_ptr(), p.numel(), float(lr), _ptr(bf16_shadow),
                                         _stream(p)), "sphip_signsgd_step")
+    timer.stop(_ev, p)
     return p
 
 
@@ -594,8 +623,10 @@ def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = Fal
     """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows."""
     _req(W, "W_dec", torch.float32, 2)
     _req(G, "W_dec.grad", torch.float32, 2)
+    _ev = timer.start("sphip_decoder_project_signsgd", W)
     check(_lib.load().sphip_decoder_project_signsgd(W.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1], float(lr),
                                                    int(renorm), _stream(W)), "sphip_decoder_project_signsgd")
+    timer.stop(_ev, W)
     return W
 
 
@@ -625,9 +656,10 @@ def gather_rows_bf16(src: Tensor, row_list: Tensor, R: int, rows_out: int) -> Te
     return dst
 
 
-def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor | None, Kd: int):
+def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor | None, Kd: int, num_valid: int | None = None):
     """Selected activations as dense bf16 matrices A (N, Kd) and A^T (Kd, ceil64(N)).
-    slot_of None: the indices are slots of the compact dead-latent numbering already."""
+    slot_of None: the indices are slots of the compact dead-latent numbering already; slots
+    >= num_valid (the padding columns of the compact selection) are dropped."""
     _req(idx, "indices", torch.int64, 2)
     _req(acts, "acts", torch.bfloat16, 2)
     if slot_of is not None:
@@ -639,7 +671,7 @@ def dead_scatter_acts(idx: Tensor, acts: Tensor, slot_of: Tensor | None, Kd: int
     A = torch.empty(N, Kd, dtype=torch.bfloat16, device=idx.device)
     At = torch.empty(Kd, ldT, dtype=torch.bfloat16, device=idx.device)
     check(_lib.load().sphip_dead_scatter_acts(idx.data_ptr(), acts.data_ptr(), _ptr(slot_of), N, k,
-                                             Kd if slot_of is None else slot_of.shape[0],
+                                             min(Kd, Kd if num_valid is None else num_valid) if slot_of is None else slot_of.shape[0],
                                              Kd, Kd, ldT, A.data_ptr(), At.data_ptr(), _stream(idx)),
           "sphip_dead_scatter_acts")
     return A, At
@@ -704,16 +736,20 @@ def mark_fired_(did_fire: Tensor, idx: Tensor) -> Tensor:
     _req(idx, "indices", torch.int64)
     _req(did_fire, "did_fire", ndim=1)
     buf = did_fire.view(torch.uint8) if did_fire.dtype == torch.bool else did_fire
+    _ev = timer.start("sphip_mark_fired", idx)
     check(_lib.load().sphip_mark_fired(idx.data_ptr(), idx.numel(), buf.shape[0], buf.data_ptr(), _stream(idx)),
           "sphip_mark_fired")
+    timer.stop(_ev, idx)
     return did_fire
 
 
 def dead_counter_step_(counts: Tensor, did_fire: Tensor, n_tokens: int) -> None:
     _req(counts, "num_tokens_since_fired", torch.int64, 1)
     buf = did_fire.view(torch.uint8) if did_fire.dtype == torch.bool else did_fire
+    _ev = timer.start("sphip_dead_counter_step", counts)
     check(_lib.load().sphip_dead_counter_step(counts.data_ptr(), buf.data_ptr(), counts.shape[0], int(n_tokens),
                                              _stream(counts)), "sphip_dead_counter_step")
+    timer.stop(_ev, counts)
 
 
 def dead_mask(counts: Tensor, threshold: int):

@@ -85,6 +85,45 @@ def all_gather_rows(x: Tensor) -> Tensor:
     return out.view(torch.bool) if as_bool else out
 
 
+def gather_rows(x: Tensor, dst: int) -> Tensor | None:
+    """(B, ...) on every rank -> (W*B, ...) in rank order on rank `dst` only, None elsewhere.
+
+    The `distribute_modules` hook (trainer.py:358-380) all-gathers every hookpoint's activations
+    to every rank and all but the owner throw them away; only the owner needs them ("scattered by
+    layer", BASELINE.json north_star; the reference's own comment at trainer.py:70 points at an
+    all-to-all). A gather to the owner moves 1/W of the all-gather's bytes over xGMI: per forward a
+    rank receives W x its own hookpoints' activations instead of W x all hookpoints'."""
+    w = world_size()
+    if w == 1:
+        return x
+    x = x.contiguous()
+    as_bool = x.dtype == torch.bool
+    src = x.view(torch.uint8) if as_bool else x
+    me = rank()
+    if _host_staged(src):
+        h = src.cpu()
+        parts = [torch.empty_like(h) for _ in range(w)] if me == dst else None
+        dist.gather(h, parts, dst=dst)
+        if me != dst:
+            return None
+        out = torch.cat(parts).to(src.device)
+    else:
+        out = src.new_empty(src.shape[0] * w, *src.shape[1:]) if me == dst else None
+        parts = list(out.chunk(w)) if me == dst else None
+        dist.gather(src, parts, dst=dst)
+        if me != dst:
+            return None
+    return out.view(torch.bool) if as_bool else out
+
+
+def module_owner(plan: list[list[str]], hookpoint: str) -> int:
+    """Rank that trains `hookpoint` under a module_plan()."""
+    for r, names in enumerate(plan):
+        if hookpoint in names:
+            return r
+    raise KeyError(hookpoint)
+
+
 class GradReducer:
     """Averages dense gradients across ranks once per optimizer step (the reference's DDP
     wrapper reduces on every micro-step backward, trainer.py:457-468, because it never uses

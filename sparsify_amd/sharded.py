@@ -29,6 +29,21 @@ from .sparse_coder import ForwardOutput, ResidualLoss
 from .utils import SparseDecode
 
 
+def merge_candidates(cand_v: Tensor, cand_i: Tensor, k: int, lo: int, hi: int):
+    """Global top-k of the gathered candidates (N, W*kk) -> (values, global indices, local view).
+
+    The candidates arrive shard-major, and inside a shard in the local top-k's order (ties in
+    ascending index order), so the top-k kernel's tie rule -- lowest position first -- is the
+    unsharded rule, lowest global index first: the merged SET equals sphip_topk over the whole
+    row. The local view holds `index - lo` for the latents this rank owns and -1 (inactive slot,
+    see sphip_gather_rows_weighted) elsewhere."""
+    mv, mpos = ops.topk(cand_v.contiguous(), k)
+    gidx = cand_i.gather(1, mpos)
+    mine = (gidx >= lo) & (gidx < hi)
+    local_idx = torch.where(mine, gidx - lo, torch.full_like(gidx, -1))
+    return mv, gidx, local_idx
+
+
 class _ShardedEncode(torch.autograd.Function):
     """Local encoder GEMM + local top-k + candidate exchange + merge. Returns the merged
     (values, global indices) and this rank's local view of the selection."""
@@ -50,10 +65,7 @@ class _ShardedEncode(torch.autograd.Function):
         kk = min(k, pre.shape[1])
         lv, li = ops.topk(pre, kk, tile_max=tile_max)
         cand_v, cand_i = parallel.gather_topk_candidates(lv, li, lo)          # (N, W*kk)
-        mv, mpos = ops.topk(cand_v.contiguous(), k)                            # merge
-        gidx = cand_i.gather(1, mpos)
-        mine = (gidx >= lo) & (gidx < hi)
-        local_idx = torch.where(mine, gidx - lo, torch.full_like(gidx, -1))    # -1 = inactive slot
+        mv, gidx, local_idx = merge_candidates(cand_v, cand_i, k, lo, hi)
         ops.forget_segments(local_idx)
         ctx.save_for_backward(rows, weight, local_idx, b_dec)
         ctx.k = k

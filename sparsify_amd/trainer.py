@@ -167,14 +167,14 @@ class Trainer:
                     if dec:
                         pgs.append(dict(params=dec, lr=lr, project_rows=True, renorm_rows=True))
                     pgs.append(dict(params=rest, lr=lr))
+                # shard / module owners hold parameters no other rank has: nothing to exchange
+                exchange = cfg.exchange_signs and not cfg.shard_latents and not cfg.distribute_modules
                 if cfg.optimizer == "signum":
-                    opt = ScheduleFreeWrapper(SignSGD(pgs, exchange_signs=cfg.exchange_signs and not cfg.shard_latents,
-                                                      overlap=cfg.overlap_exchange),
+                    opt = ScheduleFreeWrapper(SignSGD(pgs, exchange_signs=exchange, overlap=cfg.overlap_exchange),
                                               momentum=0.95)
                     opt.train()
                     self.optimizers = [opt]
                 else:
-                    exchange = cfg.exchange_signs and not cfg.shard_latents      # shard gradients are local
                     opt = SignSGD(pgs, exchange_signs=exchange, overlap=cfg.overlap_exchange)
                     self.optimizers = [opt]
                     if opt.overlap and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and cfg.loss_fn == "fvu":
@@ -182,7 +182,8 @@ class Trainer:
                         # runs: their exchange starts there (first half of the rows)
                         opt.enable_early_exchange([sae.W_dec for sae in self.saes.values() if sae.W_dec is not None])
                     one_rank = not (dist.is_initialized() and dist.get_world_size() > 1)
-                    if (cfg.fuse_encoder_update and one_rank and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
+                    # (module owners exchange no gradients either: their step can be fused as well)
+                    if (cfg.fuse_encoder_update and (one_rank or cfg.distribute_modules) and cfg.grad_acc_steps * cfg.micro_acc_steps == 1
                             and cfg.loss_fn == "fvu" and self.device.type == "cuda"):
                         opt.fuse_encoder_update([sae.encoder.weight for sae in self.saes.values()
                                                  if not opt.reduces(sae.encoder.weight)])
@@ -247,13 +248,16 @@ class Trainer:
         hook_name = name.partition("/")[0]
 
         if cfg.distribute_modules and parallel.world_size() > 1:
-            # trainer.py:358-380: every rank contributes its batch, only the owner trains
-            outputs = parallel.all_gather_rows(outputs)
+            # trainer.py:358-380: every rank contributes its batch, only the owner trains. The
+            # reference all-gathers to every rank and the non-owners drop what they received; here
+            # the batches go to the owner only (same rows in the same rank order on the owner)
+            owner = parallel.module_owner(self.module_plan, hook_name)
+            outputs = parallel.gather_rows(outputs, owner)
             if cfg.sae.transcode:
-                inputs = parallel.all_gather_rows(inputs)
+                inputs = parallel.gather_rows(inputs, owner)
             if mask is not None:
-                mask = parallel.all_gather_rows(mask)
-            if hook_name not in self.module_plan[dist.get_rank()]:
+                mask = parallel.gather_rows(mask, owner)
+            if owner != dist.get_rank():
                 return None
 
         outputs = outputs.reshape(-1, outputs.shape[-1])
@@ -443,7 +447,8 @@ class Trainer:
         the checkpoint with the lowest loss under {run}/best."""
         base_path = f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}/best'
         rank_zero = not dist.is_initialized() or dist.get_rank() == 0
-        writer = bool(self.cfg.save_dir) and (rank_zero or self.cfg.distribute_modules)
+        # (a sharded coder's save is a collective: every shard takes part, as in save())
+        writer = bool(self.cfg.save_dir) and (rank_zero or self.cfg.distribute_modules or self.cfg.shard_latents)
         if isinstance(avg_loss, dict):
             for name in self.saes:
                 if avg_loss[name] < self.best_loss[name]:
@@ -485,6 +490,11 @@ class Trainer:
             load_model(sae, f"{path}/{name}/sae.safetensors", device=str(device))
             for p in sae.parameters():
                 torch.autograd.graph.increment_version(p)
+        # a checkpoint holds the averaged iterate x and train_mode = False (the save ran between
+        # .eval() and .train(), trainer.py:652-654, 675-677): put the parameters back on y
+        for optimizer in self.optimizers:
+            if isinstance(optimizer, ScheduleFreeWrapper):
+                optimizer.train()
 
 
 def _linear_warmup_decay(optimizer, warmup: int, total: int):

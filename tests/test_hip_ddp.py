@@ -175,6 +175,9 @@ def _train_small(shard, save_dir=""):
         fvus.append(tr.last_logged["fvu/h0"])
     if save_dir:
         tr.save()
+        # save_best is a collective for latent shards too (every rank joins the gathers); it
+        # deadlocked when only rank 0 entered the checkpoint
+        tr.save_best({"h0": 0.0})
     torch.cuda.synchronize()
     sae = tr.saes["h0"]
     return {"fvu": fvus, "rows": tuple(sae.encoder.weight.shape), "W_dec": sae.W_dec.detach().cpu(),
@@ -212,6 +215,8 @@ def test_latent_sharded_trainer_matches_unsharded(device, tmp_path):
         whole = torch.cat([r0[name], r1[name]])
         assert (whole != ref[name]).float().mean() < 0.01, name
     from sparsify_amd import SparseCoder
+    best = SparseCoder.load_from_disk(tmp_path / "run" / "best" / "h0" / "h0")
+    assert torch.equal(best.W_dec.detach(), torch.cat([r0["W_dec"], r1["W_dec"]]))
     back = SparseCoder.load_from_disk(tmp_path / "run" / "h0")
     assert back.num_latents == 2048 and back.d_in == 128
     assert torch.equal(back.W_dec.detach(), torch.cat([r0["W_dec"], r1["W_dec"]]))

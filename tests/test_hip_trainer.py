@@ -178,6 +178,81 @@ def test_trainer_save_best(device, tmp_path):
     assert tr2.best_loss["h0"] == min(saved_at) and tr2.global_step == 4
 
 
+def test_resume_signum_continues_like_uninterrupted_run(device, tmp_path):
+    """Resume with the default optimizer (schedule-free SignSGD): the checkpoint holds the averaged
+    iterate x and train_mode = False (trainer.py:652-654, 675-677); load_state must put the
+    parameters back on y, after which the next steps equal those of a run that never stopped."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N, steps, stop = 64, 512, 8, 256, 7, 4
+    batches = [b.cuda() for b in make_batches(steps, N, D)]
+
+    def cfg():
+        return TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signum", save_dir=str(tmp_path),
+                           run_name="run", save_every=10**9, wandb_log_frequency=1)
+
+    torch.manual_seed(0)
+    whole = Trainer(cfg(), ListSource(batches, D), device="cuda")
+    curve = []
+    for b in batches:
+        whole.train_micro_batch({"h0": b})
+        curve.append(whole.last_logged["fvu/h0"])
+    torch.manual_seed(0)
+    first = Trainer(cfg(), ListSource(batches, D), device="cuda")
+    for b in batches[:stop]:
+        first.train_micro_batch({"h0": b})
+    first.save()
+    y_before = first.saes["h0"].W_dec.detach().clone()       # back on y after the save
+    torch.manual_seed(1)
+    second = Trainer(cfg(), ListSource(batches, D), device="cuda")
+    second.load_state(str(tmp_path / "run"))
+    assert second.global_step == stop and second.optimizers[0].train_mode
+    torch.testing.assert_close(second.saes["h0"].W_dec.detach(), y_before, rtol=0, atol=2e-7)   # x -> y -> x -> y lerps
+    resumed = []
+    for b in batches[stop:]:
+        second.train_micro_batch({"h0": b})                  # raised "call .train()" before the fix
+        resumed.append(second.last_logged["fvu/h0"])
+    for got, want in zip(resumed, curve[stop:]):
+        assert abs(got - want) <= 2e-3 * want, (resumed, curve[stop:])
+
+
+def test_bf16_shadow_and_slice_major_caches_follow_the_tensor_not_the_address(device, tmp_path):
+    """Coders loaded one after the other land at the same addresses with the same shapes and the
+    same version counters (caching allocator + load_model's copy_): the bf16 shadow of
+    encoder.weight and the slice-major copy of W_dec must not survive their parameter."""
+    import gc
+
+    import importlib
+
+    from sparsify_amd import SparseCoder, SparseCoderConfig, ops
+    fe = importlib.import_module("sparsify_amd.fused_encoder")    # (the package re-exports the function of that name)
+    D, M, k, N = 256, 16384, 16, 1024          # large enough for the L2 decode (slice-major copy)
+    cfg = SparseCoderConfig(num_latents=M, k=k)
+    x = (torch.randn(N, D, generator=torch.Generator().manual_seed(0)) + 1.0).cuda()
+    want, paths = [], []
+    for i in range(3):
+        torch.manual_seed(10 + i)
+        sae = SparseCoder(D, cfg)
+        sae.save_to_disk(tmp_path / f"c{i}")
+        paths.append(tmp_path / f"c{i}")
+        sae = sae.cuda()
+        with torch.no_grad():
+            out = sae(x)
+        want.append((out.sae_out.clone(), out.latent_indices.clone()))
+        del sae, out
+        gc.collect()
+        fe._shadows.clear(); ops._slice_major.clear()      # references computed without any cache
+    for i, path in enumerate(paths):
+        sae = SparseCoder.load_from_disk(path, device="cuda")
+        with torch.no_grad():
+            out = sae(x)
+        assert torch.equal(out.latent_indices, want[i][1]), f"coder {i} encoded with another coder's weights"
+        assert torch.equal(out.sae_out, want[i][0]), f"coder {i} decoded from another coder's W_dec"
+        del sae, out
+        gc.collect()
+    assert not fe._shadows and not ops._slice_major          # entries die with their parameters
+
+
 def test_trainer_grad_accumulation_and_k_decay(device):
     from sparsify_amd import SparseCoderConfig, TrainConfig
     from sparsify_amd.trainer import Trainer

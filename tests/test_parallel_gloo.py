@@ -47,7 +47,11 @@ def _reductions(rank, world):
     mask = P.all_gather_rows(torch.tensor([[True, False]]) if rank == 0 else torch.tensor([[False, False]]))
     with pytest.raises(ValueError):
         P.all_reduce_(x, "median")
-    return dict(mean=mean, tot=tot, fired=fired, gathered=gathered, mask=mask, lo_hi=P.shard_range(8))
+    # gather-to-owner (distribute_modules: only the hookpoint's owner receives the batches)
+    to1 = P.gather_rows(rows, 1)
+    mask_to0 = P.gather_rows(torch.tensor([[rank == 0, False]]), 0)
+    return dict(mean=mean, tot=tot, fired=fired, gathered=gathered, mask=mask, lo_hi=P.shard_range(8), to1=to1,
+                mask_to0=mask_to0)
 
 
 def test_reductions_and_gathers():
@@ -59,6 +63,9 @@ def test_reductions_and_gathers():
         assert torch.equal(r["gathered"], torch.tensor([[0., 1, 2], [3, 4, 5], [10, 11, 12], [13, 14, 15]]))
         assert r["mask"].dtype == torch.bool and r["mask"].tolist() == [[True, False], [False, False]]
     assert out[0]["lo_hi"] == (0, 4) and out[1]["lo_hi"] == (4, 8)
+    assert out[0]["to1"] is None and torch.equal(out[1]["to1"], out[1]["gathered"])
+    assert out[1]["mask_to0"] is None and out[0]["mask_to0"].dtype == torch.bool
+    assert out[0]["mask_to0"].tolist() == [[True, False], [False, False]]
 
 
 def test_module_plan():
@@ -67,6 +74,8 @@ def test_module_plan():
     assert P.module_plan(hooks, 4) == [hooks[0:2], hooks[2:4], hooks[4:6], hooks[6:8]]   # trainer.py:641-644
     with pytest.raises(AssertionError):
         P.module_plan(hooks, 3)
+    plan = P.module_plan(hooks, 4)
+    assert [P.module_owner(plan, h) for h in hooks] == [0, 0, 1, 1, 2, 2, 3, 3]
 
 
 def _grad_reducer(rank, world):
