@@ -335,6 +335,44 @@ int sphip_broadcast_rows(const float* bias, int64_t N, int64_t D, float* out, vo
 int sphip_gather_rows_bf16(const void* src, const int64_t* row_list, int64_t R, int64_t rows_out,
                            int64_t D, void* dst, void* stream);
 
+/* ---------------------------------------------------------------- Muon (muon.py:11-40, 115-181) */
+
+/* The Newton-Schulz products of quintic_newtonschulz (muon.py:34-38: A = X @ X.mT,
+ * B = b * A + c * A @ A, X = a * X + B @ X, all bf16 tensors) on the bf16 MFMA GEMM kernels:
+ *   out (N, ld_out) bf16 = rnd( rnd(alpha * rnd(x W^T)) + rnd(beta * C) ),  rnd = round to bf16,
+ * i.e. exactly the roundings torch applies to `beta * C + alpha * (x @ W.mT)` on bf16 tensors
+ * (fp32 accumulation inside the product). x (N, K), W (M, K) bf16 row-major; C (N, ld_c) bf16 or
+ * NULL (no second term). K % 8 == 0; large products (K % 64 == 0, M, ld_c, ld_out % 4 == 0) take
+ * the 256x256 LDS-DMA kernel of sphip_encoder_preacts. out must not alias x or W; it may alias C
+ * only when every tile's C is read before any of its out is written elsewhere, i.e. never rely
+ * on it. */
+int sphip_gemm_bf16_axpy(const void* x, const void* W, const void* C, void* out, int64_t N, int64_t K,
+                         int64_t M, int64_t ld_c, int64_t ld_out, float alpha, float beta, void* stream);
+
+/* Muon.step up to the orthogonalisation, one pass over the gradient (muon.py:157-160, :24, :31):
+ *   buf = lerp(buf, g, 1 - beta); u = nesterov ? lerp(g, buf, beta) : buf   (torch.lerp; beta = 0:
+ *   u = g, buf untouched and may be NULL); u_bf16 = bf16(u); norm[0] = sum(u_bf16^2) in fp32,
+ *   norm[1] = bf16(bf16(sqrt(norm[0])) + 1e-7), the denominator of `X / (X.norm() + 1e-7)` as torch
+ *   computes it on a bf16 tensor. workspace: sphip_muon_workspace_bytes() bytes.
+ * sphip_muon_denominator recomputes norm[1] from norm[0] (after the ranks of a row-sharded
+ * Newton-Schulz have summed their norm[0]); sphip_muon_normalise divides x (n bf16) by norm[1]
+ * in place, rounding to bf16. */
+size_t sphip_muon_workspace_bytes(void);
+int sphip_muon_momentum(const float* g, float* buf, int64_t n, float beta, int nesterov, void* u_bf16,
+                        float* norm, void* workspace, size_t workspace_bytes, void* stream);
+int sphip_muon_denominator(float* norm, void* stream);
+int sphip_muon_normalise(void* x, int64_t n, const float* norm, void* stream);
+
+/* dst (C, R) = src (R, C)^T, bf16 (muon.py:27-28, 39-40: the iterate is orthogonalised with
+ * rows <= columns; here it is kept tall and X X^T contracts over its transposed copy). */
+int sphip_transpose_bf16(const void* src, void* dst, int64_t R, int64_t C, void* stream);
+
+/* muon.py:121-122 + :178-180: p *= decay (= 1 - lr * weight_decay); p -= step * o with
+ * step = lr * 0.2 * sqrt(max(p.shape)) and o the bf16 orthogonalised update in p's layout.
+ * bf16_shadow (or NULL) is refreshed with bf16(p) in the same pass. */
+int sphip_muon_apply(float* p, const void* o_bf16, int64_t n, float decay, float step, void* bf16_shadow,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,13 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_mark_fired": (_I, [_P, _L, _L, _P, _P]),
     "sphip_dead_counter_step": (_I, [_P, _P, _L, _L, _P]),
     "sphip_dead_mask": (_I, [_P, _L, _L, _P, _P, _P]),
+    "sphip_gemm_bf16_axpy": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _F, _F, _P]),
+    "sphip_muon_workspace_bytes": (_Z, []),
+    "sphip_muon_momentum": (_I, [_P, _P, _L, _F, _I, _P, _P, _P, _Z, _P]),
+    "sphip_muon_denominator": (_I, [_P, _P]),
+    "sphip_muon_normalise": (_I, [_P, _L, _P, _P]),
+    "sphip_transpose_bf16": (_I, [_P, _P, _L, _L, _P]),
+    "sphip_muon_apply": (_I, [_P, _P, _L, _F, _F, _P, _P]),
 }
 
 _lib = None

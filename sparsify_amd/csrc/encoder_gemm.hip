@@ -72,12 +72,19 @@ __device__ __forceinline__ void tile_coords(int tilesM, int tilesN, int& tm, int
     tn = (int)(within / gsize);
 }
 
-template <typename T, bool RELU>
+// EPI 0: the encoder's epilogue (+ bias, ReLU, one rounding to T; P row stride M).
+// EPI 1 (bf16 only): P = rnd(rnd(alpha * rnd(acc)) + rnd(beta * C)), rnd = round to bf16 -- the
+//        roundings torch applies to `beta * C + alpha * (x @ W.mT)` on bf16 tensors (the
+//        Newton-Schulz products, sparsify/muon.py:36-38); `bias` carries C (row stride ldc, may
+//        be null: no second term), P has row stride ldp.
+template <typename T, bool RELU, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void encoder_gemm_kernel(const T* __restrict__ X,
                                                               const T* __restrict__ W,
                                                               const T* __restrict__ bias,
                                                               T* __restrict__ P, int N, int D, int M,
-                                                              int tilesM, int tilesN) {
+                                                              int tilesM, int tilesN, int64_t ldp = 0,
+                                                              int64_t ldc = 0, float alpha = 1.f,
+                                                              float beta = 0.f) {
     constexpr int EPC = GemmT<T>::EPC;
     constexpr int BKE = CHUNKS * EPC;   // K elements per tile
     __shared__ uint4 lds[2][2][TILE * CHUNKS];   // [buffer][W|X][row*8 + swizzled chunk]
@@ -154,6 +161,45 @@ __global__ __launch_bounds__(256, 2) void encoder_gemm_kernel(const T* __restric
         __syncthreads();
     }
 
+    if (EPI == 1) {
+        const bool vec = (ldp & 3) == 0 && (ldc & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wm * 64 + mi * 32 + 8 * q + 4 * h;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int n = n0 + wn * 64 + ni * 32 + r;
+                    if (n >= N || m >= M) continue;
+                    const bool whole = vec && m + 3 < M;
+                    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias != nullptr) {
+                        const T* cp = bias + (int64_t)n * ldc + m;
+                        if (whole) {
+                            const float4 c4 = load4(cp);
+                            cv[0] = c4.x, cv[1] = c4.y, cv[2] = c4.z, cv[3] = c4.w;
+                        } else {
+                            for (int j = 0; j < 4 && m + j < M; ++j) cv[j] = Elem<T>::load(cp, j);
+                        }
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = bf16_to_f32(f32_to_bf16(acc[mi][ni][4 * q + j]));
+                        if (alpha != 1.f) t = bf16_to_f32(f32_to_bf16(alpha * t));
+                        if (bias != nullptr) t += bf16_to_f32(f32_to_bf16(beta * cv[j]));
+                        v[j] = t;                       // store4 rounds once more
+                    }
+                    T* dst = P + (int64_t)n * ldp + m;
+                    if (whole) store4(dst, v, true);
+                    else
+                        for (int j = 0; j < 4 && m + j < M; ++j) Elem<T>::store(dst, j, v[j]);
+                }
+            }
+        return;
+    }
+
     // epilogue: + bias, relu, one rounding to T, 4 consecutive latents per store
     const bool vec = (M & 3) == 0;
 #pragma unroll
@@ -206,6 +252,9 @@ static int launch_gemm(const void* x, const void* W, const void* bias, void* pre
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
                          int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s,
                          int* status);   // encoder_gemm256.hip
+
+int launch_gemm256_axpy(const void* x, const void* W, const void* C, void* out, int64_t N, int64_t K, int64_t M,
+                        int64_t ld_c, int64_t ld_out, float alpha, float beta, hipStream_t s);   // encoder_gemm256.hip
 
 // Block maxima of pre for the kernels that do not take them in their epilogue (small shapes,
 // fp32): one wave per (token, 128-latent block). NaNs rank above +inf, as in topk.hip.
@@ -298,4 +347,31 @@ extern "C" int sphip_encoder_preacts_block(const void* x, const void* W, const v
         return status;
     set_error("encoder_preacts_block: D=%lld is not a multiple of 64", (long long)D);
     return SPHIP_EUNSUPPORTED;
+}
+
+extern "C" int sphip_gemm_bf16_axpy(const void* x, const void* W, const void* C, void* out, int64_t N, int64_t K,
+                                    int64_t M, int64_t ld_c, int64_t ld_out, float alpha, float beta, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(x && W && out, SPHIP_EINVAL, "gemm_bf16_axpy: null pointer");
+    SPHIP_REQUIRE(N > 0 && K > 0 && M > 0 && N < (1ll << 31) && M < (1ll << 31) && K < (1ll << 31), SPHIP_EINVAL,
+                  "gemm_bf16_axpy: bad sizes N=%lld K=%lld M=%lld", (long long)N, (long long)K, (long long)M);
+    SPHIP_REQUIRE(ld_out >= M && (C == nullptr || ld_c >= M), SPHIP_EINVAL,
+                  "gemm_bf16_axpy: row strides shorter than M (ld_c=%lld ld_out=%lld M=%lld)", (long long)ld_c,
+                  (long long)ld_out, (long long)M);
+    SPHIP_REQUIRE(K % 8 == 0, SPHIP_EUNSUPPORTED, "gemm_bf16_axpy: K=%lld must be a multiple of 8", (long long)K);
+    SPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 7) == 0 &&
+                      ((uintptr_t)C & 7) == 0, SPHIP_EINVAL, "gemm_bf16_axpy: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    // large products: the 256x256 LDS-DMA kernel (same rule as the encoder; SPHIP_GEMM=128|256 forces one)
+    const char* force = getenv("SPHIP_GEMM");
+    if (K % 64 == 0 && M % 4 == 0 && ld_out % 4 == 0 && (C == nullptr || ld_c % 4 == 0) && K * 2 * 256 < (1ll << 31) &&
+        (force ? force[0] == '2' : cdiv(M, 256) * cdiv(N, 256) >= 256))
+        return launch_gemm256_axpy(x, W, C, out, N, K, M, ld_c, ld_out, alpha, beta, s);
+    const int tilesM = (int)cdiv(M, TILE), tilesN = (int)cdiv(N, TILE);
+    SPHIP_REQUIRE((int64_t)tilesM * tilesN < (1ll << 31), SPHIP_EUNSUPPORTED, "gemm_bf16_axpy: grid too large");
+    hipLaunchKernelGGL((encoder_gemm_kernel<bf16_t, false, 1>), dim3((unsigned)(tilesM * tilesN)), dim3(256), 0, s,
+                       (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)C, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM,
+                       tilesN, ld_out, ld_c, alpha, beta);
+    SPHIP_CHECK_LAUNCH("gemm_bf16_axpy");
+    return SPHIP_OK;
 }

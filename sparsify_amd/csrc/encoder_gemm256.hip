@@ -63,12 +63,15 @@ __device__ __forceinline__ void seg_barrier() {
 
 // OUTF: 0 = the encoder's epilogue (bias, ReLU, bf16, block maxima); 1 = store the fp32
 // accumulators as they are (P is float*); 2 = add them to the fp32 values already in P
-// (sphip_gemm_bf16_f32acc: products whose fp32 operand was split into bf16 terms).
+// (sphip_gemm_bf16_f32acc: products whose fp32 operand was split into bf16 terms);
+// 3 = bf16 P = rnd(rnd(alpha * rnd(acc)) + rnd(beta * C)) with C = `bias` (row stride tilesT, may
+// be null), the Newton-Schulz products of Muon (sphip_gemm_bf16_axpy, encoder_gemm.hip).
 template <bool RELU, int DIAG, int OUTF>
 __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                              const bf16_t* __restrict__ bias, bf16_t* __restrict__ P, int N, int D,
                                              int M, int tm, int tn, bf16_t* __restrict__ tile_max, int64_t ldp,
-                                             int tilesT, unsigned* dbg, char* smem) {
+                                             int tilesT, unsigned* dbg, char* smem, float alpha = 1.f,
+                                             float beta = 0.f) {
     const int m0 = (DIAG & 16) ? (tm & 1) * G_TILE : tm * G_TILE, n0 = (DIAG & 16) ? (tn & 1) * G_TILE : tn * G_TILE;
 
     const int tid = threadIdx.x;
@@ -277,6 +280,32 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
         for (int i = 0; i < 10; ++i) o[i] = tacc[i];
     }
 
+    if (OUTF == 3) {
+        const int64_t ldc = tilesT;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + r16;
+                if (n >= N || m >= M) continue;                    // M % 4 == 0 (host check)
+                float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias != nullptr) c4 = load4(bias + (int64_t)n * ldc + m);
+                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+                bf16_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = bf16_to_f32(f32_to_bf16(acc[mi][ni][j]));
+                    if (alpha != 1.f) t = bf16_to_f32(f32_to_bf16(alpha * t));
+                    if (bias != nullptr) t += bf16_to_f32(f32_to_bf16(beta * cv[j]));
+                    o[j] = f32_to_bf16(t);
+                }
+                *reinterpret_cast<uint2*>(P + (int64_t)n * ldp + m) =
+                    make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+            }
+        }
+        return;
+    }
     if (OUTF != 0) {
         // fp32 output: the lane's 4 consecutive columns of one row per accumulator tile, 16-B
         // pieces straight from the registers (these products write N x M / K-fold fewer bytes
@@ -407,7 +436,8 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                                                                  bf16_t* __restrict__ P, int N, int D, int M,
                                                                  int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
                                                                  int64_t ldp, int tilesT, int bandh,
-                                                                 unsigned* dbg = nullptr) {
+                                                                 unsigned* dbg = nullptr, float alpha = 1.f,
+                                                                 float beta = 0.f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned nb = (unsigned)tilesM * (unsigned)tilesN;
     for (unsigned vb = blockIdx.x; vb < nb; vb += gridDim.x) {
@@ -420,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         const unsigned first = g * (unsigned)bandh;
         const unsigned gsize = min((unsigned)tilesM - first, (unsigned)bandh);
         gemm256_tile<RELU, DIAG, OUTF>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
-                                       tile_max, ldp, tilesT, dbg, smem);
+                                       tile_max, ldp, tilesT, dbg, smem, alpha, beta);
         if (vb + gridDim.x < nb) __syncthreads();      // the next tile's staging overwrites the epilogue area
     }
 }
@@ -537,6 +567,26 @@ int launch_gemm256_f32out(const void* x, const void* W, float* out, int64_t N, i
                            (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
                            (bf16_t*)nullptr, ld_out, 0, gemm_band());
     SPHIP_CHECK_LAUNCH("gemm_bf16_f32acc");
+    return SPHIP_OK;
+}
+
+// bf16 out = rnd(rnd(alpha * rnd(x W^T)) + rnd(beta * C)): see OUTF 3 above.
+int launch_gemm256_axpy(const void* x, const void* W, const void* C, void* out, int64_t N, int64_t K, int64_t M,
+                        int64_t ld_c, int64_t ld_out, float alpha, float beta, hipStream_t s) {
+    const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
+    SPHIP_REQUIRE(ld_c < (1ll << 31), SPHIP_EUNSUPPORTED, "gemm_bf16_axpy: ld_c exceeds int32");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPHIP_REQUIRE(hipFuncSetAttribute((const void*)encoder_gemm256_kernel<false, 0, 3>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES) == hipSuccess,
+                      SPHIP_ELAUNCH, "gemm_bf16_axpy: cannot reserve %d bytes of LDS", G_LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)tilesM * tilesN)), block(512);
+    hipLaunchKernelGGL((encoder_gemm256_kernel<false, 0, 3>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
+                       (const bf16_t*)W, (const bf16_t*)C, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
+                       (bf16_t*)nullptr, ld_out, (int)ld_c, gemm_band(), (unsigned*)nullptr, alpha, beta);
+    SPHIP_CHECK_LAUNCH("gemm_bf16_axpy");
     return SPHIP_OK;
 }
 

@@ -731,6 +731,89 @@ def broadcast_rows(bias: Tensor, N: int) -> Tensor:
     return out
 
 
+# ------------------------------------------------------------------ Muon (muon.hip + the GEMM axpy epilogue)
+def gemm_bf16_axpy(x: Tensor, W: Tensor, C: Tensor | None = None, alpha: float = 1.0, beta: float = 0.0,
+                   out: Tensor | None = None) -> Tensor:
+    """bf16 out (N, M) = rnd(rnd(alpha * rnd(x @ W.T)) + rnd(beta * C)): torch's roundings for
+    `beta * C + alpha * (x @ W.mT)` on bf16 tensors (muon.py:36-38)."""
+    _req(x, "x", torch.bfloat16, 2)
+    _req(W, "W", torch.bfloat16, 2)
+    N, K = x.shape
+    M = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError(f"gemm_bf16_axpy: x {tuple(x.shape)} vs W {tuple(W.shape)}")
+    if C is not None:
+        _req(C, "C", torch.bfloat16, 2)
+        if tuple(C.shape) != (N, M):
+            raise ValueError(f"gemm_bf16_axpy: C {tuple(C.shape)} is not ({N}, {M})")
+    if out is None:
+        out = torch.empty(N, M, dtype=torch.bfloat16, device=x.device)
+    _req(out, "out", torch.bfloat16, 2)
+    if tuple(out.shape) != (N, M) or out.data_ptr() in (x.data_ptr(), W.data_ptr()):
+        raise ValueError("gemm_bf16_axpy: out must be a separate (N, M) tensor")
+    _ev = timer.start("sphip_gemm_bf16_axpy", x)
+    check(_lib.load().sphip_gemm_bf16_axpy(x.data_ptr(), W.data_ptr(), _ptr(C), out.data_ptr(), N, K, M, M, M, float(alpha),
+                                          float(beta), _stream(x)), "sphip_gemm_bf16_axpy")
+    timer.stop(_ev, x)
+    return out
+
+
+def muon_momentum(g: Tensor, buf: Tensor | None, beta: float, nesterov: bool):
+    """(bf16 update u, norm = [sum(u^2), denominator]); buf is updated in place (muon.py:157-160)."""
+    _req(g, "grad", torch.float32)
+    if buf is not None:
+        _req(buf, "momentum buffer", torch.float32)
+        if buf.shape != g.shape:
+            raise ValueError("muon_momentum: buffer shape mismatch")
+    elif beta > 0:
+        raise ValueError("muon_momentum: momentum needs a buffer")
+    u = torch.empty(g.shape, dtype=torch.bfloat16, device=g.device)
+    norm = torch.empty(2, dtype=torch.float32, device=g.device)
+    lib = _lib.load()
+    ws = _workspace(g.device, lib.sphip_muon_workspace_bytes(), "muon")
+    check(lib.sphip_muon_momentum(g.data_ptr(), _ptr(buf), g.numel(), float(beta), int(nesterov), u.data_ptr(),
+                                  norm.data_ptr(), ws.data_ptr(), ws.numel(), _stream(g)), "sphip_muon_momentum")
+    return u, norm
+
+
+def muon_denominator_(norm: Tensor) -> Tensor:
+    _req(norm, "norm", torch.float32, 1)
+    check(_lib.load().sphip_muon_denominator(norm.data_ptr(), _stream(norm)), "sphip_muon_denominator")
+    return norm
+
+
+def muon_normalise_(x: Tensor, norm: Tensor) -> Tensor:
+    _req(x, "x", torch.bfloat16)
+    _req(norm, "norm", torch.float32, 1)
+    check(_lib.load().sphip_muon_normalise(x.data_ptr(), x.numel(), norm.data_ptr(), _stream(x)), "sphip_muon_normalise")
+    return x
+
+
+def transpose_bf16(src: Tensor, out: Tensor | None = None) -> Tensor:
+    _req(src, "src", torch.bfloat16, 2)
+    R, C = src.shape
+    if out is None:
+        out = torch.empty(C, R, dtype=torch.bfloat16, device=src.device)
+    _req(out, "out", torch.bfloat16, 2)
+    if tuple(out.shape) != (C, R):
+        raise ValueError("transpose_bf16: out shape mismatch")
+    check(_lib.load().sphip_transpose_bf16(src.data_ptr(), out.data_ptr(), R, C, _stream(src)), "sphip_transpose_bf16")
+    return out
+
+
+def muon_apply_(p: Tensor, o: Tensor, decay: float, step: float, bf16_shadow: Tensor | None = None) -> Tensor:
+    """p = p * decay - step * o (muon.py:121-122, 178-180), o bf16 in p's layout."""
+    _req(p, "param", torch.float32)
+    _req(o, "update", torch.bfloat16)
+    if o.numel() != p.numel():
+        raise ValueError("muon_apply: size mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    check(_lib.load().sphip_muon_apply(p.data_ptr(), o.data_ptr(), p.numel(), float(decay), float(step), _ptr(bf16_shadow),
+                                      _stream(p)), "sphip_muon_apply")
+    return p
+
+
 # ------------------------------------------------------------------ dead-latent bookkeeping
 def mark_fired_(did_fire: Tensor, idx: Tensor) -> Tensor:
     _req(idx, "indices", torch.int64)
