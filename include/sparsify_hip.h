@@ -177,6 +177,16 @@ size_t sphip_reduce_workspace_bytes(int64_t N, int64_t D);
 int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64_t D, float* tv,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* sphip_total_variance for callers that cannot allocate or pass a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc). No counterpart in the reference.
+ * Same kernels and the same result, bit for bit; the partial sums live in a file-scope device
+ * array of the library (8.06 MiB per GPU the library runs on, held until the process ends)
+ * instead of a workspace, so the call allocates nothing and takes no workspace argument.
+ * Limit: D <= 8192 (SPHIP_EUNSUPPORTED beyond; use sphip_total_variance). Calls that overlap on
+ * one GPU (different streams or threads) share that GPU's array and race: serialise them. */
+int sphip_total_variance_static(const void* y, int y_dtype, int64_t N, int64_t D, float* tv,
+                                void* stream);
+
 /* sparse_coder.py:225,253 (and :248, :260 with other operands): e = a - b; sq[0] = sum(e^2).
  * a (N,D) of a_dtype, b (N,D) fp32, e (N,D) fp32 or NULL. */
 int sphip_residual_sumsq(const void* a, int a_dtype, const float* b, float* e, float* sq,

@@ -44,6 +44,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_segmented_weight_grad": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P]),
     "sphip_reduce_workspace_bytes": (_Z, [_L, _L]),
     "sphip_total_variance": (_I, [_P, _I, _L, _L, _P, _P, _Z, _P]),
+    "sphip_total_variance_static": (_I, [_P, _I, _L, _L, _P, _P]),
     "sphip_residual_sumsq": (_I, [_P, _I, _P, _P, _P, _L, _L, _P, _Z, _P]),
     "sphip_scale_by_ratio": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "sphip_colsum": (_I, [_P, _I, _L, _L, _F, _P, _P, _Z, _P]),

@@ -243,14 +243,13 @@ extern "C" int sphip_vec_mat(const float* v, const float* W, int64_t M, int64_t 
     return SPHIP_OK;
 }
 
-extern "C" int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64_t D, float* tv, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+static int total_variance_impl(const void* y, int y_dtype, int64_t N, int64_t D, float* tv, void* workspace,
+                               size_t workspace_bytes, hipStream_t s) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(y_dtype), SPHIP_EINVAL, "total_variance: bad dtype");
     SPHIP_REQUIRE(y && tv, SPHIP_EINVAL, "total_variance: null pointer");
     SPHIP_REQUIRE(N > 0 && D > 0 && D < (1ll << 31), SPHIP_EINVAL, "total_variance: bad shape");
     SPHIP_WS_CHECK("total_variance");
-    hipStream_t s = (hipStream_t)stream;
     launch_col_partial<false>(y, y_dtype, nullptr, N, D, partial, s);
     hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)cdiv(D, 256)), dim3(256), 0, s, partial, num_chunks(N), (int)D, 1.0f / (float)N, meanbuf);
     const int rp = rows_per_chunk(N), nc = num_chunks(N);
@@ -267,6 +266,52 @@ extern "C" int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64
     hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, s, scal, (int)(gx * nc), tv);
     SPHIP_CHECK_LAUNCH("total_variance");
     return SPHIP_OK;
+}
+
+extern "C" int sphip_total_variance(const void* y, int y_dtype, int64_t N, int64_t D, float* tv, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return total_variance_impl(y, y_dtype, N, D, tv, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- the allocation-free form: the partial sums live in a file-scope device array instead of a
+// caller-provided workspace. Every GPU the library runs on holds its own copy of the array (at its
+// own address) until the process ends; the host-side name `tv_scratch` is only a handle for
+// hipGetSymbolAddress, the kernels get the resolved per-device pointer like any other workspace.
+namespace sphip {
+constexpr int64_t TV_STATIC_MAX_D = 8192;
+// red_plan(N, 8192): 256 x 8192 x 4 (column partials) + 8192 x 4 (mean) + 8192 x 4 (scalar partials)
+constexpr size_t TV_STATIC_BYTES = (size_t)RED_ROWS * TV_STATIC_MAX_D * 4 + 2 * (size_t)TV_STATIC_MAX_D * 4;
+}  // namespace sphip
+static __device__ __align__(256) unsigned char tv_scratch[sphip::TV_STATIC_BYTES];
+
+#include <mutex>
+extern "C" int sphip_total_variance_static(const void* y, int y_dtype, int64_t N, int64_t D, float* tv, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(D > 0 && D <= TV_STATIC_MAX_D, SPHIP_EUNSUPPORTED,
+                  "total_variance_static: D=%lld exceeds the built-in scratch (D <= %lld); use sphip_total_variance "
+                  "with a caller workspace", (long long)D, (long long)TV_STATIC_MAX_D);
+    SPHIP_REQUIRE(N > 0 && red_plan(N, D).total <= TV_STATIC_BYTES, SPHIP_EUNSUPPORTED,
+                  "total_variance_static: shape N=%lld D=%lld does not fit the built-in scratch", (long long)N, (long long)D);
+    constexpr int MAX_DEV = 64;
+    static void* dev_ptr[MAX_DEV] = {nullptr};
+    static std::mutex mu;
+    int dev = -1;
+    SPHIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEV, SPHIP_ELAUNCH,
+                  "total_variance_static: no current device");
+    void* ptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev_ptr[dev] == nullptr) {
+            // once per device, with that device current: the address of THIS device's copy
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(tv_scratch));
+            SPHIP_REQUIRE(e == hipSuccess && p != nullptr, SPHIP_ELAUNCH, "total_variance_static: hipGetSymbolAddress: %s",
+                          hipGetErrorString(e));
+            dev_ptr[dev] = p;
+        }
+        ptr = dev_ptr[dev];
+    }
+    return total_variance_impl(y, y_dtype, N, D, tv, ptr, TV_STATIC_BYTES, (hipStream_t)stream);
 }
 
 extern "C" int sphip_residual_sumsq(const void* a, int a_dtype, const float* b, float* e, float* sq, int64_t N,
