@@ -373,9 +373,19 @@ int sphip_muon_momentum(const float* g, float* buf, int64_t n, float beta, int n
 int sphip_muon_denominator(float* norm, void* stream);
 int sphip_muon_normalise(void* x, int64_t n, const float* norm, void* stream);
 
-/* dst (C, R) = src (R, C)^T, bf16 (muon.py:27-28, 39-40: the iterate is orthogonalised with
- * rows <= columns; here it is kept tall and X X^T contracts over its transposed copy). */
-int sphip_transpose_bf16(const void* src, void* dst, int64_t R, int64_t C, void* stream);
+/* dst (C, ld_dst) = src (R, C)^T for bf16 or fp32 elements; R <= ld_dst < R + 64, the padding
+ * columns R..ld_dst-1 are written as zeros (so that a product contracting over R can round R up
+ * to the multiple its kernel needs). Used where the reference transposes views for free:
+ * muon.py:27-28, 39-40 (the Newton-Schulz iterate; here kept tall, X X^T contracts over its
+ * transposed copy) and the backward of the skip term `x @ W_skip.mT` (sparse_coder.py:221-222:
+ * W_skip.grad = g^T x contracts over the tokens). */
+int sphip_transpose(const void* src, void* dst, int64_t R, int64_t C, int64_t ld_dst, int dtype,
+                    void* stream);
+
+/* out = a + b, n elements, a and out fp32, b bf16 or fp32: `sae_out += x @ W_skip.mT`
+ * (sparse_coder.py:221-222; under autocast the product is a bf16 tensor and the sum fp32).
+ * out may be a. */
+int sphip_add(const float* a, const void* b, int b_dtype, float* out, int64_t n, void* stream);
 
 /* muon.py:121-122 + :178-180: p *= decay (= 1 - lr * weight_decay); p -= step * o with
  * step = lr * 0.2 * sqrt(max(p.shape)) and o the bf16 orthogonalised update in p's layout.

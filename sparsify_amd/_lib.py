@@ -78,7 +78,8 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_muon_momentum": (_I, [_P, _P, _L, _F, _I, _P, _P, _P, _Z, _P]),
     "sphip_muon_denominator": (_I, [_P, _P]),
     "sphip_muon_normalise": (_I, [_P, _L, _P, _P]),
-    "sphip_transpose_bf16": (_I, [_P, _P, _L, _L, _P]),
+    "sphip_transpose": (_I, [_P, _P, _L, _L, _L, _I, _P]),
+    "sphip_add": (_I, [_P, _P, _I, _P, _L, _P]),
     "sphip_muon_apply": (_I, [_P, _P, _L, _F, _F, _P, _P]),
 }
 

@@ -105,20 +105,40 @@ __global__ __launch_bounds__(MU_THREADS) void scale_bf16_kernel(bf16_t* __restri
     }
 }
 
-// dst (C, R) = src (R, C)^T, 64 x 64 tiles through LDS; both sides move 128-byte row pieces.
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                            int64_t R, int64_t C) {
-    __shared__ bf16_t tile[64][66];
+// dst (C, ld) = src (R, C)^T, 64 x 64 tiles through LDS; both sides move contiguous row pieces.
+// Columns R..ld-1 of dst (padding up to a multiple the GEMM's contraction needs) are zero-filled.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t R,
+                                                       int64_t C, int64_t ld) {
+    __shared__ T tile[64][65 + (sizeof(T) == 2 ? 1 : 0)];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int64_t r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? src[r * C + c] : (bf16_t)0;
+        tile[i][tx] = (r < R && c < C) ? src[r * C + c] : (T)0;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int64_t c = c0 + i, r = r0 + tx;
-        if (c < C && r < R) dst[c * R + r] = tile[tx][i];
+        if (c < C && r < ld) dst[c * ld + r] = tile[tx][i];        // rows past R were staged as zeros
+    }
+}
+
+// out = a (fp32) + b (bf16 or fp32): the skip term's product added to the reconstruction
+// (sparse_coder.py:221-222; under autocast the product is a bf16 tensor, the sum fp32)
+template <typename T>
+__global__ __launch_bounds__(MU_THREADS) void add_kernel(const float* __restrict__ a, const T* __restrict__ b,
+                                                        float* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * MU_THREADS * MU_VEC;
+    for (int64_t i = ((int64_t)blockIdx.x * MU_THREADS + threadIdx.x) * MU_VEC; i < n; i += stride) {
+        if (i + MU_VEC <= n) {
+            float4 d = *reinterpret_cast<const float4*>(a + i);
+            const float4 y = load4(b + i);
+            d.x += y.x, d.y += y.y, d.z += y.z, d.w += y.w;
+            *reinterpret_cast<float4*>(out + i) = d;
+        } else {
+            for (int64_t e = i; e < n; ++e) out[e] = a[e] + Elem<T>::load(b, e);
+        }
     }
 }
 
@@ -201,14 +221,37 @@ extern "C" int sphip_muon_normalise(void* x, int64_t n, const float* norm, void*
     return SPHIP_OK;
 }
 
-extern "C" int sphip_transpose_bf16(const void* src, void* dst, int64_t R, int64_t C, void* stream) {
+extern "C" int sphip_transpose(const void* src, void* dst, int64_t R, int64_t C, int64_t ld_dst, int dtype,
+                               void* stream) {
     using namespace sphip;
-    SPHIP_REQUIRE(src && dst && src != dst, SPHIP_EINVAL, "transpose_bf16: null or aliased pointers");
-    SPHIP_REQUIRE(R > 0 && C > 0 && cdiv(R, 64) < 65536 && cdiv(C, 64) < (1ll << 31), SPHIP_EINVAL,
-                  "transpose_bf16: bad shape R=%lld C=%lld", (long long)R, (long long)C);
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R, C);
-    SPHIP_CHECK_LAUNCH("transpose_bf16");
+    SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "transpose: bad dtype %d", dtype);
+    SPHIP_REQUIRE(src && dst && src != dst, SPHIP_EINVAL, "transpose: null or aliased pointers");
+    SPHIP_REQUIRE(R > 0 && C > 0 && ld_dst >= R && ld_dst < R + 64 && cdiv(ld_dst, 64) < 65536 && cdiv(C, 64) < (1ll << 31),
+                  SPHIP_EINVAL, "transpose: bad shape R=%lld C=%lld ld_dst=%lld (R <= ld_dst < R + 64)", (long long)R,
+                  (long long)C, (long long)ld_dst);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(ld_dst, 64)), block(256);
+    if (dtype == SPHIP_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst,
+                           R, C, ld_dst);
+    else
+        hipLaunchKernelGGL((transpose_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, (float*)dst, R,
+                           C, ld_dst);
+    SPHIP_CHECK_LAUNCH("transpose");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_add(const float* a, const void* b, int b_dtype, float* out, int64_t n, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(b_dtype), SPHIP_EINVAL, "add: bad dtype %d", b_dtype);
+    SPHIP_REQUIRE(a && b && out && n > 0, SPHIP_EINVAL, "add: null pointer or empty tensor");
+    SPHIP_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)b & (b_dtype == SPHIP_BF16 ? 7 : 15)) == 0,
+                  SPHIP_EINVAL, "add: misaligned tensor");
+    const dim3 grid(stream_blocks(n, MU_VEC * 4)), block(MU_THREADS);
+    if (b_dtype == SPHIP_BF16)
+        hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a, (const bf16_t*)b, out, n);
+    else
+        hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (const float*)b, out, n);
+    SPHIP_CHECK_LAUNCH("add");
     return SPHIP_OK;
 }
 

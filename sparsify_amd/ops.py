@@ -789,15 +789,33 @@ def muon_normalise_(x: Tensor, norm: Tensor) -> Tensor:
     return x
 
 
+def transpose(src: Tensor, out: Tensor | None = None, pad_to: int = 1) -> Tensor:
+    """(R, C) -> (C, ld) with ld = R rounded up to a multiple of pad_to, padding columns zero."""
+    _req(src, "src", ndim=2)
+    R, C = src.shape
+    ld = -(-R // pad_to) * pad_to
+    if out is None:
+        out = torch.empty(C, ld, dtype=src.dtype, device=src.device)
+    _req(out, "out", src.dtype, 2)
+    if tuple(out.shape) != (C, ld):
+        raise ValueError(f"transpose: out must be ({C}, {ld})")
+    check(_lib.load().sphip_transpose(src.data_ptr(), out.data_ptr(), R, C, ld, _dt(src), _stream(src)), "sphip_transpose")
+    return out
+
+
 def transpose_bf16(src: Tensor, out: Tensor | None = None) -> Tensor:
     _req(src, "src", torch.bfloat16, 2)
-    R, C = src.shape
-    if out is None:
-        out = torch.empty(C, R, dtype=torch.bfloat16, device=src.device)
-    _req(out, "out", torch.bfloat16, 2)
-    if tuple(out.shape) != (C, R):
-        raise ValueError("transpose_bf16: out shape mismatch")
-    check(_lib.load().sphip_transpose_bf16(src.data_ptr(), out.data_ptr(), R, C, _stream(src)), "sphip_transpose_bf16")
+    return transpose(src, out)
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    """fp32 a + b (b bf16 or fp32, same number of elements) as a new fp32 tensor of a's shape."""
+    _req(a, "a", torch.float32)
+    _req(b, "b")
+    if b.numel() != a.numel():
+        raise ValueError("add: size mismatch")
+    out = torch.empty_like(a)
+    check(_lib.load().sphip_add(a.data_ptr(), b.data_ptr(), _dt(b), out.data_ptr(), a.numel(), _stream(a)), "sphip_add")
     return out
 
 

@@ -65,6 +65,70 @@ class ResidualLoss(torch.autograd.Function):
         return ops.scale_by_ratio(e, -2.0, g, tv).reshape(ctx.pred_shape), None, None
 
 
+class _AddSkip(torch.autograd.Function):
+    """sae_out + skip with sae_out fp32 and skip bf16 (autocast) or fp32, one pass; both
+    gradients are the incoming one (the product's backward casts it as autocast would)."""
+
+    @staticmethod
+    def forward(ctx, sae_out: Tensor, skip: Tensor):
+        ctx.set_materialize_grads(False)
+        return ops.add(sae_out.contiguous(), skip.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class SkipProduct(torch.autograd.Function):
+    """x @ W_skip.mT (sparse_coder.py:221-222) on the package's own GEMM kernels.
+
+    Under bf16 autocast the reference's matmul takes bf16 operands and returns a bf16 tensor, and
+    its backward runs in bf16 too (the fp32 gradient of sae_out is cast, W_skip.grad = g^T x is
+    produced in bf16 and cast to the fp32 parameter): sphip_gemm_bf16_axpy with those roundings.
+    Without autocast everything is the exact-fp32 MFMA product (sphip_encoder_preacts, relu off)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, W: Tensor, low: bool):
+        parallel.wait_for(W)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        ctx.low, ctx.x_shape = low, x.shape
+        if low:
+            xl = low_precision_input(x2, None)
+            wl = ops.cast_bf16(W.detach().contiguous())
+            out = ops.gemm_bf16_axpy(xl, wl)
+            ctx.save_for_backward(xl, wl)
+        else:
+            xf = x2 if x2.dtype == torch.float32 else ops.center_cast(x2, None, True, False)[0]
+            out = ops.encoder_preacts(xf, W.detach().contiguous(), None, relu=False)
+            ctx.save_for_backward(xf, W)
+        ctx.set_materialize_grads(False)
+        return out.reshape(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        xs, ws = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        gx = gW = None
+        if ctx.low:
+            gl = g2 if g2.dtype == torch.bfloat16 else ops.center_cast(g2 if g2.dtype == torch.float32 else g2.float(),
+                                                                       None, False, True)[1]
+            if ctx.needs_input_grad[1]:
+                # g^T x contracts over the tokens: both operands transposed, the token count
+                # padded with zero columns to the kernel's multiple of 8
+                gW = ops.gemm_bf16_axpy(ops.transpose(gl, pad_to=8), ops.transpose(xs, pad_to=8)).float()
+            if ctx.needs_input_grad[0]:
+                gx = ops.gemm_bf16_axpy(gl, ops.transpose(ws)).reshape(ctx.x_shape)
+        else:
+            gf = g2 if g2.dtype == torch.float32 else g2.float()
+            if ctx.needs_input_grad[1]:
+                gW = ops.encoder_preacts(ops.transpose(gf, pad_to=4), ops.transpose(xs, pad_to=4), None, relu=False)
+            if ctx.needs_input_grad[0]:
+                gx = ops.encoder_preacts(gf, ops.transpose(ws.detach().contiguous()), None, relu=False).reshape(ctx.x_shape)
+        return gx, gW, None
+
+
 class SparseCoder(nn.Module):
     def __init__(
         self,
@@ -191,8 +255,9 @@ class SparseCoder(nn.Module):
 
         sae_out = self.decode(top_acts, top_indices)
         if self.W_skip is not None:
-            parallel.wait_for(self.W_skip)
-            sae_out = sae_out + x.to(self.dtype) @ self.W_skip.mT
+            from .fused_encoder import _autocast_bf16
+            skip = SkipProduct.apply(x, self.W_skip, _autocast_bf16())
+            sae_out = _AddSkip.apply(sae_out, skip)
 
         y2 = y.reshape(-1, y.shape[-1]).contiguous()
         total_variance = ops.total_variance(y2)                     # sparse_coder.py:228

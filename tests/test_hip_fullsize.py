@@ -143,3 +143,41 @@ def test_auxk_dense_products_against_row_gather(state):
         err = float((a - b_).abs().max())
         assert err <= 2e-5 * scale, f"{what}: max abs difference {err:.3e} at scale {scale:.3e}"
     assert not bool(res["dense"][1][~dead].any())
+
+
+def test_k_decay_start_k_40960(state):
+    """The first steps of a run with k-decay use k = min(M, 10 d_in) = 40960 latents per token
+    (sparsify/trainer.py:176-177, 229-235): top-k, decode and both weight gradients at that k on a
+    small batch of the headline dictionary. Checked against dense torch expressions of the same
+    quantities (a (tokens x M) matrix of the selected activations times the table)."""
+    from sparsify_amd import ops
+    n, k = 48, 40960
+    pre = state["pre"][:n].contiguous()
+    vals, idx = ops.topk(pre, k, tile_max=state["tmax"][:1].contiguous())
+    # exact selection: the k-th largest value, nothing above it left out, values gathered from the row
+    assert torch.equal(pre.gather(1, idx), vals)
+    assert int((idx.sort(dim=1).values.diff(dim=1) == 0).sum()) == 0
+    kth = pre.float().kthvalue(M - k + 1, dim=1).values
+    assert torch.equal(vals.float().min(dim=1).values, kth)
+    assert int(((pre.float() > kth[:, None]).sum(dim=1)).max()) <= k - 1
+    # ties at the boundary (relu zeros): the lowest indices win
+    for r in (0, n - 1):
+        row = pre[r].float()
+        below = (row == kth[r]).nonzero().flatten()
+        need = k - int((row > kth[r]).sum())
+        chosen = idx[r][vals[r].float() == kth[r]].sort().values
+        assert torch.equal(chosen, below[:need])
+    # decode + gradients against the dense form
+    W = state["W"]
+    acts = vals.float()
+    A = torch.zeros(n, M, device="cuda").scatter_(1, idx, acts)
+    out = ops.gather_rows_weighted(idx, acts, W)
+    ref = A.double() @ W.double()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4)
+    g = torch.randn(n, D, device="cuda", generator=state["gen"])
+    seg = ops.build_latent_segments(idx, M)
+    gW, gb, dc = ops.segmented_weight_grad(seg, acts, g, W, want_bias=True, want_dcoeff=True)
+    torch.testing.assert_close(gW.double(), A.double().T @ g.double(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gb.double(), A.double().sum(0), rtol=1e-6, atol=1e-6)
+    dense_dc = g.double() @ W.double().T                                   # (n, M)
+    torch.testing.assert_close(dc.double(), dense_dc.gather(1, idx), rtol=1e-5, atol=1e-5)

@@ -313,3 +313,43 @@ def test_schedulefree_fused_step_equals_generic_path(device, monkeypatch, D):
     for a, c in ((xf[0], xg[0]), (zf[0], zg[0])):
         bad = (a - c).abs() > 1e-5
         assert bad.float().mean() < 2e-3
+
+
+@pytest.mark.parametrize("D", [64, 1000, 4096])
+def test_schedulefree_kernels_vs_independent_oracle(device, D):
+    """sphip_schedulefree_signsgd_step / sphip_decoder_schedulefree_signsgd_step over ten steps against
+    oracle/schedule_free_oracle.py, a float64 statement of the published algorithm that shares no
+    code with sparsify_amd/schedule_free.py (PARITY UNPINNED: the `schedulefree` package the
+    reference imports is not available; see the oracle's header). Decoder rows: projection w.r.t.
+    y, step, re-normalisation of y."""
+    from oracle.schedule_free_oracle import ScheduleFreeSignSGD
+    from sparsify_amd import ops
+    M, steps, lr, beta = 80, 10, 3e-3, 0.95
+    gen = torch.Generator().manual_seed(D)
+    W0 = O.unit_norm_rows(torch.randn(M, D, generator=gen))
+    E0 = torch.randn(M, D, generator=gen)
+    ora_d, ora_e = ScheduleFreeSignSGD(W0, lr, beta), ScheduleFreeSignSGD(E0, lr, beta)
+    Wy, Wz = W0.clone().cuda(), W0.clone().cuda()
+    Ey, Ez = E0.clone().cuda(), E0.clone().cuda()
+    shadow = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    for t in range(steps):
+        gd, ge = torch.randn(M, D, generator=gen), torch.randn(M, D, generator=gen)
+        c = ora_d.step(gd, project_rows=True, renorm_rows=True)
+        assert ora_e.step(ge) == c and abs(c - 1.0 / (t + 1)) < 1e-12            # constant lr: c = 1 / (t + 1)
+        ops.decoder_schedulefree_signsgd_step_(Wy, Wz, gd.cuda(), lr, beta, c, renorm=True)
+        ops.schedulefree_signsgd_step_(Ey, Ez, ge.cuda(), lr, beta, c, shadow)
+        # plain parameters: every element to fp32 rounding of a value of size ~1, every step
+        torch.testing.assert_close(Ey.cpu().double(), ora_e.y, rtol=0, atol=2e-6)
+        torch.testing.assert_close(Ez.cpu().double(), ora_e.z, rtol=0, atol=2e-6)
+        assert torch.equal(shadow, Ey.bfloat16())
+        # decoder rows: the sign of a projected component within rounding of zero may differ, which
+        # moves that element by 2 lr; anything else is fp32 rounding
+        for got, want in ((Wy, ora_d.y), (Wz, ora_d.z)):
+            bad = (got.cpu().double() - want).abs() > 2e-6
+            assert bad.double().mean() < 1e-3, (t, float(bad.double().mean()))
+        # keep the two runs on the same trajectory (a flipped sign is legitimate, not an error to compound)
+        ora_d.y, ora_d.z = Wy.cpu().double(), Wz.cpu().double()
+    torch.testing.assert_close(Wy.norm(dim=1).cpu(), torch.ones(M), rtol=0, atol=1e-6)
+    # .eval(): x = lerp(y, z, 1 - 1/beta) as schedule_free.ScheduleFreeWrapper.eval computes it
+    x = torch.lerp(Ey, Ez, 1 - 1 / beta)
+    torch.testing.assert_close(x.cpu().double(), ora_e.eval_weights(), rtol=0, atol=5e-6)
