@@ -226,9 +226,12 @@ int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16
  * followed by the SignSGD step on W, one pass over (W, G). renorm != 0 additionally applies
  * set_decoder_norm_to_unit_norm (sparse_coder.py:273-279) to the updated rows in the same
  * pass -- the normalisation that opens the next train step (trainer.py:408); the result is
- * bitwise that of the step followed by sphip_unit_norm_rows. */
+ * bitwise that of the step followed by sphip_unit_norm_rows.
+ * slice_major (or NULL): the [D/32][M][32] copy of W that sphip_gather_rows_weighted_l2 reads
+ * (sphip_slice_major_f32) is rewritten from the finished rows while they are in registers, so
+ * the next decode needs no separate copy pass; D % 32 == 0. */
 int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr,
-                                  int renorm, void* stream);
+                                  int renorm, float* slice_major, void* stream);
 
 /* ---------------------------------------------------------------- dead-latent bookkeeping */
 

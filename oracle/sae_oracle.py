@@ -246,6 +246,29 @@ def forward_backward(
     return out, grads
 
 
+def backward_from_output_grad(P: dict[str, Tensor], xin: Tensor, idx: Tensor, acts: Tensor, g: Tensor,
+                              cfg: OracleConfig):
+    """Parameter gradients (and the gradient w.r.t. the encoder input) of any scalar loss, given
+    g = dL/d sae_out for sae_out = decode(acts, idx): the decoder backward (xformers.py:88-136), the
+    cast of dL/d top_acts to the dtype of top_acts (backward of sparse_coder.py:201) and the
+    encoder backward over the selected columns (fused_encoder.py:52-87). This is what the
+    end-to-end losses (trainer.py:425-430, 486-500) send through a coder: there g comes out of the
+    language model instead of the FVU. `xin` is the encoder input (x - b_dec for autoencoders)."""
+    W_enc, W_dec = P["W_enc"], P["W_dec"]
+    M = W_enc.shape[0]
+    g = g.float()
+    gW_dec = scatter_rows(idx, acts.to(torch.float32), g, M)
+    gb_dec = g.sum(0)
+    d_acts = torch.einsum("nd,nsd->ns", g, W_dec[idx])
+    gv = d_acts.to(acts.dtype)
+    gW_enc = scatter_rows(idx, gv, xin, M)
+    gb_enc = scatter_scalar(idx, gv, M)
+    g_xin = gather_sum(idx, gv.to(W_enc.dtype), W_enc)
+    if not cfg.transcode:
+        gb_dec = gb_dec - g_xin.sum(0)
+    return {"W_enc": gW_enc, "b_enc": gb_enc, "W_dec": gW_dec, "b_dec": gb_dec}, g_xin
+
+
 def fused_encoder_fwd_bwd(x, W, b, k, activation, grad_values):
     """FusedEncoder forward + backward for an arbitrary upstream grad on the values
     (fused_encoder.py:20-87); mirrors tests/test_encode.py:43-47 when grad_values == 1."""

@@ -120,9 +120,13 @@ __global__ __launch_bounds__(256) void decoder_row_kernel(float* __restrict__ W,
 // updated row (optimizer step + the re-normalisation that opens the next train step,
 // trainer.py:408). The reductions add in the same order as the two-sweep kernels above, so
 // results are bitwise identical to them.
-template <int R, int OP>
+// SM (needs D % 32 == 0): the finished row also goes to the slice-major copy [D/32][M][32] the
+// L2-resident decode gathers from (sphip_slice_major_f32), while it is in registers: the separate
+// copy pass (2 GiB read + 2 GiB written at the headline shape) becomes 2 GiB of extra stores.
+template <int R, int OP, bool SM = false>
 __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __restrict__ W, const float* __restrict__ G,
-                                                                   int D, float lr, float eps) {
+                                                                   int D, float lr, float eps,
+                                                                   float* __restrict__ sm = nullptr, int64_t M = 0) {
     __shared__ float red[16];
     float* w = W + (int64_t)blockIdx.x * D;
     const float* g = G + (int64_t)blockIdx.x * D;
@@ -169,15 +173,29 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        const int c = (threadIdx.x + 256 * i) * 4;
-        if (c < D) *reinterpret_cast<float4*>(w + c) = b[i];
+        const int c4 = threadIdx.x + 256 * i;               // 16-byte chunk of the row
+        const int c = c4 * 4;
+        if (c < D) {
+            *reinterpret_cast<float4*>(w + c) = b[i];
+            // slice c4 / 8, piece of row blockIdx.x, chunk c4 % 8: eight threads write one 128-byte line
+            if (SM) *reinterpret_cast<float4*>(sm + (((int64_t)(c4 >> 3) * M + blockIdx.x) * 8 + (c4 & 7)) * 4) = b[i];
+        }
     }
 }
 
 template <int OP>
-static bool launch_row_resident(float* W, const float* G, int64_t M, int64_t D, float lr, float eps, hipStream_t s) {
+static bool launch_row_resident(float* W, const float* G, int64_t M, int64_t D, float lr, float eps, hipStream_t s,
+                                float* sm = nullptr) {
     if (D % 4 != 0 || D > 8192 || ((uintptr_t)W & 15) != 0 || ((uintptr_t)G & 15) != 0) return false;
     dim3 grid((unsigned)M), block(256);
+    if (sm != nullptr) {
+        if (D % 32 != 0 || ((uintptr_t)sm & 15) != 0) return false;
+        if (D <= 1024) hipLaunchKernelGGL((decoder_row_resident_kernel<1, OP, true>), grid, block, 0, s, W, G, (int)D, lr, eps, sm, M);
+        else if (D <= 2048) hipLaunchKernelGGL((decoder_row_resident_kernel<2, OP, true>), grid, block, 0, s, W, G, (int)D, lr, eps, sm, M);
+        else if (D <= 4096) hipLaunchKernelGGL((decoder_row_resident_kernel<4, OP, true>), grid, block, 0, s, W, G, (int)D, lr, eps, sm, M);
+        else hipLaunchKernelGGL((decoder_row_resident_kernel<8, OP, true>), grid, block, 0, s, W, G, (int)D, lr, eps, sm, M);
+        return true;
+    }
     if (D <= 1024) hipLaunchKernelGGL((decoder_row_resident_kernel<1, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
     else if (D <= 2048) hipLaunchKernelGGL((decoder_row_resident_kernel<2, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
     else if (D <= 4096) hipLaunchKernelGGL((decoder_row_resident_kernel<4, OP>), grid, block, 0, s, W, G, (int)D, lr, eps);
@@ -638,20 +656,23 @@ extern "C" int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, i
 }
 
 extern "C" int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D, float lr, int renorm,
-                                             void* stream) {
+                                             float* slice_major, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W && G, SPHIP_EINVAL, "decoder_project_signsgd: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "decoder_project_signsgd: bad shape");
+    SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0), SPHIP_EINVAL,
+                  "decoder_project_signsgd: the slice-major copy needs D %% 32 == 0 and a 16-byte aligned buffer");
     hipStream_t s = (hipStream_t)stream;
-    const bool done = renorm ? launch_row_resident<2>(W, G, M, D, lr, SPHIP_F32_EPS, s)
-                             : launch_row_resident<1>(W, G, M, D, lr, SPHIP_F32_EPS, s);
+    const bool done = renorm ? launch_row_resident<2>(W, G, M, D, lr, SPHIP_F32_EPS, s, slice_major)
+                             : launch_row_resident<1>(W, G, M, D, lr, SPHIP_F32_EPS, s, slice_major);
     if (done) {
         SPHIP_CHECK_LAUNCH("decoder_project_signsgd");
         return SPHIP_OK;
     }
-    const int st = decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
-    if (st != SPHIP_OK || !renorm) return st;
-    return sphip_unit_norm_rows(W, M, D, stream);
+    int st = decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
+    if (st == SPHIP_OK && renorm) st = sphip_unit_norm_rows(W, M, D, stream);
+    if (st == SPHIP_OK && slice_major != nullptr) st = sphip_slice_major_f32(W, slice_major, M, D, stream);
+    return st;
 }
 
 extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow, void* stream) {

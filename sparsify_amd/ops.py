@@ -243,6 +243,31 @@ def slice_major_copy(table: Tensor) -> Tensor:
     return buf
 
 
+def peek_slice_major(table: Tensor) -> Tensor | None:
+    """The (possibly stale) slice-major buffer of `table`, for an update kernel to rewrite."""
+    hit = _slice_major.get(table.data_ptr())
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if owner is None or owner.data_ptr() != table.data_ptr() or owner.shape != table.shape:
+        return None
+    return hit[2]
+
+
+def register_slice_major(table: Tensor, buf: Tensor) -> None:
+    """Tell the cache that `buf` holds the slice-major copy of `table` as it is now (a fused
+    optimizer step wrote it)."""
+    import weakref
+    key = table.data_ptr()
+
+    def _drop(ref, key=key):
+        cur = _slice_major.get(key)
+        if cur is not None and cur[0] is ref:
+            del _slice_major[key]
+
+    _slice_major[key] = (weakref.ref(table, _drop), (table._version, tuple(table.shape)), buf)
+
+
 def slice_major_copy_of(table: Tensor, owner: Tensor | None) -> Tensor | None:
     if owner is None or owner.data_ptr() != table.data_ptr() or owner.shape != table.shape:
         return None
@@ -619,13 +644,19 @@ def decoder_schedulefree_apply_signs_(W: Tensor, Z: Tensor, signs: Tensor, lr: f
     return W
 
 
-def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = False) -> Tensor:
-    """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows."""
+def decoder_project_signsgd_(W: Tensor, G: Tensor, lr: float, renorm: bool = False,
+                             slice_major: Tensor | None = None) -> Tensor:
+    """W -= lr * sign(G - <G,W> W) per row; renorm=True also re-normalises the updated rows;
+    slice_major: the [D/32][M][32] buffer to rewrite with the finished rows in the same pass."""
     _req(W, "W_dec", torch.float32, 2)
     _req(G, "W_dec.grad", torch.float32, 2)
+    if slice_major is not None:
+        _req(slice_major, "slice_major", torch.float32)
+        if slice_major.numel() != W.numel() or W.shape[1] % 32:
+            raise ValueError("decoder_project_signsgd: slice-major buffer does not match W")
     _ev = timer.start("sphip_decoder_project_signsgd", W)
     check(_lib.load().sphip_decoder_project_signsgd(W.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1], float(lr),
-                                                   int(renorm), _stream(W)), "sphip_decoder_project_signsgd")
+                                                   int(renorm), _ptr(slice_major), _stream(W)), "sphip_decoder_project_signsgd")
     timer.stop(_ev, W)
     return W
 

@@ -3,6 +3,8 @@ p -= lr * sign(grad) is one HIP pass per parameter, which can also refresh the b
 the encoder GEMM reads (so the next step needs no separate cast)."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.optim import Optimizer
 
@@ -112,8 +114,12 @@ class SignSGD(Optimizer):
                     # (sparse_coder.py:281-295) fused with the sign step, one pass over (W, G);
                     # "renorm_rows" also applies the set_decoder_norm_to_unit_norm that opens
                     # the next train step (trainer.py:408) while the rows are in registers
-                    ops.decoder_project_signsgd_(p.data, g, lr, renorm)
+                    # (the slice-major copy the L2-resident decode reads is rewritten in the same pass)
+                    sm = ops.peek_slice_major(p) if os.environ.get("SPHIP_SM_FOLD", "1") != "0" else None
+                    ops.decoder_project_signsgd_(p.data, g, lr, renorm, slice_major=sm)
                     torch.autograd.graph.increment_version(p)
+                    if sm is not None:
+                        ops.register_slice_major(p, sm)
                     if renorm:
                         self.renormalised.add(id(p))
                     continue

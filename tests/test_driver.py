@@ -105,6 +105,99 @@ def test_model_trainer_equals_trainer_on_captured_activations(device, transcode)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transcode", [False, True])
+def test_model_trainer_follows_the_oracle_loop(device, transcode):
+    """The driver against the CPU oracle (pinned to the reference): the coders of one hookpoint are
+    given the oracle's initialisation, the model's activations are captured with plain hooks, and
+    the oracle's train loop (trainer.py:392-447, 510-522 restated) runs on exactly those tokens
+    (excluded tokens dropped, trainer.py:383-390). FVU step by step, as
+    tests/test_hip_trainer.py::test_trainer_matches_oracle_loop."""
+    from oracle import sae_oracle as O
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.driver import ModelTrainer
+    model = tiny_lm().cuda()
+    S, B, steps, vocab, M, k, lr = 32, 16, 8, 128, 512, 8, 2e-3
+    data = torch.randint(0, vocab, (B * steps, S), generator=torch.Generator().manual_seed(4))
+    point = "layers.1.mlp" if transcode else "layers.1"
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, transcode=transcode), optimizer="signsgd", lr=lr,
+                      hookpoints=[point], batch_size=B, exclude_tokens=[0, 5], save_dir="", save_every=10**9,
+                      wandb_log_frequency=1)
+    mt = ModelTrainer(cfg, data, model)
+    P = O.init_params(64, M, transcode=transcode, seed=0)
+    sae = mt.saes[point]
+    with torch.no_grad():
+        sae.encoder.weight.copy_(P["W_enc"]); sae.encoder.bias.copy_(P["b_enc"])
+        sae.W_dec.copy_(P["W_dec"]); sae.b_dec.copy_(P["b_dec"])
+    curve = []
+    flush = mt._flush_metrics
+
+    def spy(step):
+        flush(step)
+        curve.append(mt.last_logged[f"fvu/{point}"])
+
+    mt._flush_metrics = spy
+    mt.fit()
+    assert len(curve) == steps
+    cap = _Capture(model, [point], transcode)
+    ocfg = O.OracleConfig(k=k, transcode=transcode)
+    for s in range(steps):
+        x = data[s * B: (s + 1) * B].cuda()
+        keep = torch.isin(x, torch.tensor([0, 5], device="cuda"), invert=True).reshape(-1).cpu()
+        got = cap(x)[point]
+        xin, y = ((got[0].flatten(0, 1).cpu()[keep], got[1].flatten(0, 1).cpu()[keep]) if transcode
+                  else (got.flatten(0, 1).cpu()[keep], None))
+        want = float(O.train_step_signsgd(P, xin, y, ocfg, lr, step=s, bf16=True)["fvu"])
+        tol = 2e-3 if s == 0 else 8e-2          # bf16 tie picks decorrelate the runs slowly
+        assert abs(curve[s] - want) <= tol * want, (s, curve[s], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_fn", ["ce", "kl"])
+def test_end_to_end_loss_coder_gradients_match_the_oracle(device, loss_fn):
+    """loss_fn 'ce' / 'kl': whatever gradient the language model sends into a coder's output, the
+    coder's parameter gradients are those of the CPU oracle (oracle.backward_from_output_grad: the
+    reference's decoder / cast / fused-encoder backward, pinned by the goldens) for the same
+    dL/d sae_out, the same tokens and the same selected latents -- to the bf16 tolerance of the
+    other oracle comparisons (2e-3 of the gradient's norm), both hookpoints, the second of which
+    receives its input through the first coder's spliced reconstruction."""
+    from oracle import sae_oracle as O
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.driver import ModelTrainer
+    model = tiny_lm().cuda()
+    S, B, vocab = 32, 8, 128
+    data = torch.randint(0, vocab, (B, S), generator=torch.Generator().manual_seed(3))
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=512, k=8), optimizer="signsgd", lr=1e-3, loss_fn=loss_fn,
+                      hookpoints=["layers.0", "layers.2"], batch_size=B, grad_acc_steps=2,      # no optimizer step yet
+                      save_dir="", save_every=10**9, wandb_log_frequency=1)
+    mt = ModelTrainer(cfg, data, model)
+    seen = {}
+    orig = mt.train_on_activations
+
+    def spy(name, inputs, outputs, mask=None, e2e=False):
+        out, n = orig(name, inputs, outputs, mask, e2e=e2e)
+        rec = {"x": outputs.detach().reshape(-1, outputs.shape[-1]).float().cpu(), "idx": out.latent_indices.detach().cpu(),
+               "acts": out.latent_acts.detach().cpu(),
+               "P": {"W_enc": mt.saes[name].encoder.weight.detach().cpu().clone(),
+                     "b_enc": mt.saes[name].encoder.bias.detach().cpu().clone(),
+                     "W_dec": mt.saes[name].W_dec.detach().cpu().clone(), "b_dec": mt.saes[name].b_dec.detach().cpu().clone()}}
+        out.sae_out.register_hook(lambda g, rec=rec: rec.__setitem__("g", g.detach().reshape(-1, g.shape[-1]).float().cpu()))
+        seen[name] = rec
+        return out, n
+
+    mt.train_on_activations = spy
+    mt.fit()
+    assert set(seen) == {"layers.0", "layers.2"} and all("g" in r for r in seen.values())
+    ocfg = O.OracleConfig(k=8)
+    for name, r in seen.items():
+        want, _ = O.backward_from_output_grad(r["P"], r["x"] - r["P"]["b_dec"], r["idx"], r["acts"], r["g"], ocfg)
+        sae = mt.saes[name]
+        got = {"W_enc": sae.encoder.weight.grad, "b_enc": sae.encoder.bias.grad, "W_dec": sae.W_dec.grad, "b_dec": sae.b_dec.grad}
+        for pname, gr in got.items():
+            rel = (gr.cpu() - want[pname]).norm() / want[pname].norm().clamp_min(1e-20)
+            assert rel < 2e-3, f"{name}.{pname}: relative error {rel:.3e}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("loss_fn", ["ce", "kl"])
 def test_end_to_end_loss_gradients_match_torch_autograd(device, loss_fn):
     """loss_fn 'ce' / 'kl' (trainer.py:425-430, 486-500): the model's loss is back-propagated through

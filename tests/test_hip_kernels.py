@@ -720,3 +720,26 @@ def test_slice_major_copy_ragged(device, R, D):
     t = dev(torch.randn(R, D))
     sm = ops.slice_major_copy(t)
     assert torch.equal(sm, t.view(R, D // 32, 32).transpose(0, 1))
+
+
+@pytest.mark.parametrize("D,renorm", [(256, True), (4096, True), (1056, False), (8192, True)])
+def test_decoder_step_writes_the_slice_major_copy(device, D, renorm):
+    """sphip_decoder_project_signsgd with a slice-major buffer: the parameter is bit for bit what the
+    call without the buffer leaves, and the buffer equals sphip_slice_major_f32 of the updated
+    parameter (what the L2-resident decode would otherwise have to copy)."""
+    from sparsify_amd import _lib, ops
+    from sparsify_amd._lib import check
+    M = 1000
+    g = torch.Generator(device="cuda").manual_seed(D)
+    W0 = torch.randn(M, D, device="cuda", generator=g)
+    W0 /= W0.norm(dim=1, keepdim=True)
+    G = torch.randn(M, D, device="cuda", generator=g)
+    plain = ops.decoder_project_signsgd_(W0.clone(), G, 3e-3, renorm)
+    buf = torch.full((D // 32, M, 32), float("nan"), device="cuda")
+    got = ops.decoder_project_signsgd_(W0.clone(), G, 3e-3, renorm, slice_major=buf)
+    assert torch.equal(got, plain)
+    want = torch.empty_like(buf)
+    check(_lib.load().sphip_slice_major_f32(got.data_ptr(), want.data_ptr(), M, D, None), "sphip_slice_major_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    assert torch.equal(buf, got.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
