@@ -127,26 +127,82 @@ def module_owner(plan: list[list[str]], hookpoint: str) -> int:
 class GradReducer:
     """Averages dense gradients across ranks once per optimizer step (the reference's DDP
     wrapper reduces on every micro-step backward, trainer.py:457-468, because it never uses
-    no_sync()). ``finish()`` is called right before the optimizer step: one all-reduce per
-    parameter, enqueued in parameter order on every rank; with RCCL the calls are
-    stream-ordered (no host sync) and run back to back over all xGMI links."""
+    no_sync()).
 
-    def __init__(self, params):
+    Large gradients (>= `bucket_bytes`: the (M, D) matrices under Adam / Muon) are all-reduced one
+    by one, asynchronously, from a post-accumulate-grad hook -- i.e. inside the backward, as soon
+    as the gradient is complete, on the communication stream and under the rest of the backward --
+    whenever the reducer is `armed` (the Trainer arms it for the last micro-step of an optimizer
+    step). Everything else (biases, b_dec) is packed into one flat bucket and reduced by a single
+    call in ``finish()``, which also waits for the asynchronous ones; it runs right before the
+    optimizer step. Without arming (plain use, CPU tests) ``finish()`` does all of it itself.
+    With RCCL every call is stream-ordered (no host sync)."""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20):
         self.params = [p for p in params]
+        self.bucket_bytes = bucket_bytes
+        self.armed = False
+        self._inflight: list = []           # (param, work) of asynchronous all-reduces
+        self._done: set[int] = set()
+        self._hooks = []
+        if world_size() > 1:
+            for p in self.params:
+                if self._large(p) and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _large(self, p) -> bool:
+        return p.numel() * p.element_size() >= self.bucket_bytes
+
+    def _on_grad(self, p) -> None:
+        if not self.armed or p.grad is None or id(p) in self._done or _host_staged(p.grad):
+            return
+        g = p.grad if p.grad.is_contiguous() else None
+        if g is None:
+            return
+        avg = dist.get_backend() == "nccl"
+        work = dist.all_reduce(g, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._inflight.append((p, work, avg))
+        self._done.add(id(p))
 
     def finish(self):
         w = world_size()
         if w == 1:
             return
         avg = dist.get_backend() == "nccl"
-        for p in self.params:
-            if p.grad is None:
-                continue
-            if avg:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
-            else:
-                _all_reduce_raw(p.grad, dist.ReduceOp.SUM)
+        for p, work, was_avg in self._inflight:
+            work.wait()                              # stream-ordered under RCCL
+            if not was_avg:
                 p.grad /= w
+        small = []
+        for p in self.params:
+            if p.grad is None or id(p) in self._done:
+                continue
+            if self._large(p):
+                if avg:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+                else:
+                    _all_reduce_raw(p.grad, dist.ReduceOp.SUM)
+                    p.grad /= w
+            else:
+                small.append(p)
+        if small:
+            # one flat bucket for the small ones; a dtype of its own per group
+            by_dtype: dict = {}
+            for p in small:
+                by_dtype.setdefault(p.grad.dtype, []).append(p)
+            for group in by_dtype.values():
+                flat = torch.cat([p.grad.reshape(-1) for p in group])
+                if avg:
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                else:
+                    _all_reduce_raw(flat, dist.ReduceOp.SUM)
+                    flat /= w
+                o = 0
+                for p in group:
+                    n = p.grad.numel()
+                    p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                    o += n
+        self._inflight, self._done, self.armed = [], set(), False
 
 
 # ------------------------------------------------------------------ overlapped updates
@@ -169,29 +225,30 @@ def exchange_stream(device: torch.device) -> "torch.cuda.Stream":
 
 
 def set_pending(t: Tensor, blocks: list) -> None:
-    _pending[t.data_ptr()] = blocks
+    _pending[t.data_ptr()] = (t.device, blocks)
 
 
 def pending_blocks(t: Tensor) -> list | None:
     """[(row_lo, row_hi, event)] of an update of `t` that may still be running, else None.
     The caller takes over: it must wait for every event before reading those rows."""
-    return _pending.pop(t.data_ptr(), None)
+    hit = _pending.pop(t.data_ptr(), None)
+    return None if hit is None else hit[1]
 
 
 def wait_for(t: Tensor) -> None:
     """Make the current stream wait until `t` holds its last update."""
-    blocks = _pending.pop(t.data_ptr(), None)
-    if blocks:
+    hit = _pending.pop(t.data_ptr(), None)
+    if hit and hit[1]:
         cur = torch.cuda.current_stream(t.device)
-        cur.wait_event(blocks[-1][2])              # blocks finish in order on one stream
+        cur.wait_event(hit[1][-1][2])              # blocks finish in order on one stream
 
 
 def wait_for_updates() -> None:
-    """Make the current stream of every device wait for all overlapped updates."""
-    for blocks in _pending.values():
+    """Make the current stream of every device that has an overlapped update in flight wait for
+    it (an event belongs to the device of the parameter it was recorded for)."""
+    for device, blocks in _pending.values():
         if blocks:
-            ev = blocks[-1][2]
-            torch.cuda.current_stream().wait_event(ev)
+            torch.cuda.current_stream(device).wait_event(blocks[-1][2])
     _pending.clear()
 
 

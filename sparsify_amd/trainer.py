@@ -235,6 +235,14 @@ class Trainer:
         self._reducer = parallel.GradReducer([p for p in params if not any(f(p) for f in own)])
         self._hooks_installed = True
 
+    def _arm_grad_reduce(self):
+        """Last micro-step of an optimizer step: the large gradients may leave for their all-reduce
+        from inside this backward (parallel.GradReducer). One backward per hookpoint and step: with
+        several coders the hooks of each fire in its own backward."""
+        red = getattr(self, "_reducer", None)
+        if red is not None and (self.global_step + 1) % self.cfg.grad_acc_steps == 0:
+            red.armed = True
+
     def _finish_grad_reduce(self):
         if getattr(self, "_reducer", None) is not None:
             self._reducer.finish()
@@ -313,6 +321,7 @@ class Trainer:
 
         acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
         loss = out.fvu + cfg.auxk_alpha * out.auxk_loss + out.multi_topk_fvu / 8    # trainer.py:444-446
+        self._arm_grad_reduce()
         loss.div(acc_steps).backward()
         return out, n_tokens
 

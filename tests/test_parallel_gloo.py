@@ -94,8 +94,32 @@ def _grad_reducer(rank, world):
     return [p.grad.clone() for p in model.parameters()], data
 
 
-def test_grad_reducer_matches_global_average():
-    out = launch(_grad_reducer)
+def _grad_reducer_async(rank, world):
+    """The same with the weight counted as a large gradient: its all-reduce leaves from the
+    post-accumulate hook of the LAST micro-step's backward (armed), the bias goes into the flat
+    bucket of finish()."""
+    from sparsify_amd import parallel as P
+    torch.manual_seed(0)
+    model = torch.nn.Linear(5, 3)
+    P.broadcast_parameters(model.parameters())
+    acc = 2
+    red = P.GradReducer(model.parameters(), bucket_bytes=40)        # weight 60 B: large; bias 12 B: bucket
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(world * acc, 4, 5, generator=g)
+    launched = []
+    for micro in range(acc):
+        red.armed = micro == acc - 1
+        x = data[rank * acc + micro]
+        (model(x).pow(2).mean() / acc).backward()
+        launched.append(len(red._inflight))
+    red.finish()
+    assert launched == [0, 1] and not red._inflight and not red.armed
+    return [p.grad.clone() for p in model.parameters()], data
+
+
+@pytest.mark.parametrize("fn", [_grad_reducer, _grad_reducer_async])
+def test_grad_reducer_matches_global_average(fn):
+    out = launch(fn)
     (g0, data), (g1, _) = out
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)               # replicas hold identical gradients
