@@ -265,6 +265,16 @@ int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg
                                         void* stream);
 int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                              int coeff_dtype, int64_t M, float* out, void* stream);
+/* The same fusion for the reference's default optimizer "signum" (schedule-free SignSGD,
+ * trainer.py:146-162; see sphip_schedulefree_signsgd_step for the update and its parity status):
+ * each finished gradient row piece drives the schedule-free step of (param = y, z) in place.
+ * Bit for bit sphip_segmented_weight_grad followed by sphip_schedulefree_signsgd_step. */
+int sphip_segmented_weight_grad_schedulefree(const uint32_t* perm, const int32_t* seg_begin,
+                                             const void* coeff, int coeff_dtype, const void* rows,
+                                             int rows_dtype, const float* row_shift, int64_t N,
+                                             int64_t k, int64_t M, int64_t D, float* param, float* z,
+                                             float lr, float beta, float c, void* bf16_shadow,
+                                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Sign exchange for data-parallel SignSGD (DDP gradient exchange, trainer.py:457-468, done as
  * reduce-scatter of the fp32 gradients + all-gather of 1-byte signs instead of an all-reduce:

@@ -138,4 +138,23 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// ---- schedule-free SignSGD element update (dense.hip; fused into the weight-gradient kernels)
+// lerp(a, b, w) = |w| < 0.5 ? a + w (b - a) : b - (b - a)(1 - w), as torch.lerp.
+__device__ __forceinline__ float lerpf(float a, float b, float w) {
+    const float d = b - a;
+    return fabsf(w) < 0.5f ? fmaf(w, d, a) : fmaf(-d, 1.f - w, b);
+}
+// x = lerp(y, z, w_undo); z -= lr sign; x = lerp(x, z, c); y = lerp(x, z, w_y)
+__device__ __forceinline__ void sf_update(float& y, float& z, float sgn, float lr, float w_undo, float c, float w_y) {
+    const float x = lerpf(y, z, w_undo);
+    z = z - lr * sgn;
+    const float x2 = lerpf(x, z, c);
+    y = lerpf(x2, z, w_y);
+}
+// Arguments of the schedule-free form of a fused step: z == nullptr means plain SignSGD.
+struct SfArgs {
+    float* z;
+    float w_undo, c, w_y;
+};
+
 }  // namespace sphip

@@ -375,16 +375,7 @@ __global__ __launch_bounds__(256) void apply_signs_norm_kernel(float* __restrict
 //     x' = lerp(x, z', c)                  (c = w_t / sum w)
 //     y' = lerp(x', z', 1 - beta)
 // lerp(a, b, w) = |w| < 0.5 ? a + w (b - a) : b - (b - a)(1 - w), as torch.lerp.
-__device__ __forceinline__ float lerpf(float a, float b, float w) {
-    const float d = b - a;
-    return fabsf(w) < 0.5f ? fmaf(w, d, a) : fmaf(-d, 1.f - w, b);
-}
-__device__ __forceinline__ void sf_update(float& y, float& z, float sgn, float lr, float w_undo, float c, float w_y) {
-    const float x = lerpf(y, z, w_undo);
-    z = z - lr * sgn;
-    const float x2 = lerpf(x, z, c);
-    y = lerpf(x2, z, w_y);
-}
+// (lerpf / sf_update: common.hpp, shared with the fused encoder-gradient kernels of wgrad.hip)
 
 __global__ __launch_bounds__(256) void sf_signsgd_kernel(float* __restrict__ p, float* __restrict__ zb,
                                                          const float* __restrict__ g, int64_t n, float lr,

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                                                                bf16_t* __restrict__ shadow = nullptr,
                                                                const int* __restrict__ skew = nullptr, int skew_T = 0,
                                                                const float* __restrict__ Wdot = nullptr,
-                                                               float* __restrict__ slab = nullptr, int64_t E = 0) {
+                                                               float* __restrict__ slab = nullptr, int64_t E = 0,
+                                                               SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // a workgroup holds 32 latents for as long as its longest segment lasts: with `skew` set,
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     float bsum = 0.f;
     // FUSE: the parameter piece is requested now and used after the segment loop
     float wold[FUSE ? C : 1];
+    float zold[FUSE ? C : 1];               // schedule-free form (sf.z != nullptr): the base iterate
     if (FUSE && live) {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
@@ -213,6 +215,10 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gW + (int64_t)j * D + col + c));
             wold[c] = t[0], wold[c + 1] = t[1], wold[c + 2] = t[2], wold[c + 3] = t[3];
+            if (sf.z != nullptr) {
+                const f4 u = __builtin_nontemporal_load(reinterpret_cast<const f4*>(sf.z + (int64_t)j * D + col + c));
+                zold[c] = u[0], zold[c + 1] = u[1], zold[c + 2] = u[2], zold[c + 3] = u[3];
+            }
         }
     }
     float wdot[DOT ? C : 1];
@@ -339,11 +345,24 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
                 f4 w = {wold[c], wold[c + 1], wold[c + 2], wold[c + 3]};
+                if (sf.z != nullptr) {
+                    f4 z = {zold[c], zold[c + 1], zold[c + 2], zold[c + 3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g = acc[c + e];
-                    w[e] -= lr * (float)((g > 0.f) - (g < 0.f));
-                    sh[c + e] = f32_to_bf16(w[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = acc[c + e];
+                        float y1 = w[e], z1 = z[e];
+                        sf_update(y1, z1, (float)((g > 0.f) - (g < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+                        w[e] = y1, z[e] = z1;
+                        sh[c + e] = f32_to_bf16(y1);
+                    }
+                    __builtin_nontemporal_store(z, reinterpret_cast<f4*>(sf.z + (int64_t)j * D + col + c));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = acc[c + e];
+                        w[e] -= lr * (float)((g > 0.f) - (g < 0.f));
+                        sh[c + e] = f32_to_bf16(w[e]);
+                    }
                 }
                 __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o + c));
             }
@@ -397,7 +416,7 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
                                             const RT* __restrict__ rows, const float* __restrict__ W,
                                             float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
                                             const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
-                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow);
+                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow, SfArgs sf);
 
 template <typename RT, bool DOT, bool FUSE = false, bool LIST = false>
 __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __restrict__ packed,
@@ -409,7 +428,8 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
                                                              int64_t E, int M, int D,
                                                              const int* __restrict__ skew = nullptr, int skew_T = 0,
                                                              float lr = 0.f, bf16_t* __restrict__ shadow = nullptr,
-                                                             int slice0 = 0) {
+                                                             int slice0 = 0,
+                                                             SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = blockIdx.y + slice0;
@@ -419,12 +439,12 @@ __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __rest
         const int n_long = skew[0];
         for (int i = wv; i < n_long; i += (int)gridDim.x * 4)
             wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D,
-                                       __builtin_amdgcn_readfirstlane(skew[1 + i]), slice, lane, lr, shadow);
+                                       __builtin_amdgcn_readfirstlane(skew[1 + i]), slice, lane, lr, shadow, sf);
         return;
     }
     if (wv >= M) return;
     wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D, wv, slice, lane, lr,
-                               shadow);
+                               shadow, sf);
 }
 
 template <typename RT, bool DOT, bool FUSE>
@@ -432,7 +452,7 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
                                             const RT* __restrict__ rows, const float* __restrict__ W,
                                             float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
                                             const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
-                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow) {
+                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow, SfArgs sf) {
     const int col = slice * 256 + lane * 4;
     const int beg = seg_begin[j], end = seg_begin[j + 1];
     // W and gW are streamed once: non-temporal, so that they do not displace the resident slice of `rows`
@@ -514,10 +534,19 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
     }
     if (FUSE) {       // gW is the parameter: SignSGD step in place (see seg_wgrad_sliced_kernel)
         float4 p4 = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col);
-        p4.x -= lr * (float)((acc.x > 0.f) - (acc.x < 0.f));
-        p4.y -= lr * (float)((acc.y > 0.f) - (acc.y < 0.f));
-        p4.z -= lr * (float)((acc.z > 0.f) - (acc.z < 0.f));
-        p4.w -= lr * (float)((acc.w > 0.f) - (acc.w < 0.f));
+        if (sf.z != nullptr) {
+            float4 z4 = *reinterpret_cast<const float4*>(sf.z + (int64_t)j * D + col);
+            sf_update(p4.x, z4.x, (float)((acc.x > 0.f) - (acc.x < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+            sf_update(p4.y, z4.y, (float)((acc.y > 0.f) - (acc.y < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+            sf_update(p4.z, z4.z, (float)((acc.z > 0.f) - (acc.z < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+            sf_update(p4.w, z4.w, (float)((acc.w > 0.f) - (acc.w < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+            *reinterpret_cast<float4*>(sf.z + (int64_t)j * D + col) = z4;
+        } else {
+            p4.x -= lr * (float)((acc.x > 0.f) - (acc.x < 0.f));
+            p4.y -= lr * (float)((acc.y > 0.f) - (acc.y < 0.f));
+            p4.z -= lr * (float)((acc.z > 0.f) - (acc.z < 0.f));
+            p4.w -= lr * (float)((acc.w > 0.f) - (acc.w < 0.f));
+        }
         *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = p4;
         if (shadow != nullptr) {
             const unsigned lo = (unsigned)f32_to_bf16(p4.x) | ((unsigned)f32_to_bf16(p4.y) << 16);
@@ -601,7 +630,7 @@ template <typename RT, bool FUSE = false, bool DOT = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
                           float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr,
-                          const float* Wdot = nullptr, float* slab = nullptr) {
+                          const float* Wdot = nullptr, float* slab = nullptr, SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -617,7 +646,7 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     if (nblocks >= (1ll << 31)) return false;
     hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                        (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k);
+                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf);
     return true;
 }
 
@@ -814,11 +843,10 @@ extern "C" int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg
     return SPHIP_OK;
 }
 
-extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
-                                                   int coeff_dtype, const void* rows, int rows_dtype,
-                                                   const float* row_shift, int64_t N, int64_t k, int64_t M, int64_t D,
-                                                   float* param, float lr, void* bf16_shadow, void* workspace,
-                                                   size_t workspace_bytes, void* stream) {
+static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype,
+                                  const void* rows, int rows_dtype, const float* row_shift, int64_t N, int64_t k,
+                                  int64_t M, int64_t D, float* param, float lr, void* bf16_shadow, void* workspace,
+                                  size_t workspace_bytes, void* stream, sphip::SfArgs sf) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad_signsgd: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && param, SPHIP_EINVAL, "segmented_weight_grad_signsgd: null pointer");
@@ -850,19 +878,42 @@ extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const i
         hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
     }
     const bool done = rows_dtype == SPHIP_F32
-                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew)
-                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew);
+                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf)
+                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf);
     SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
     if (skew != nullptr) {
         const FastDiv kd = make_fastdiv((unsigned)k);
         dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
         if (rows_dtype == SPHIP_F32)
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, true, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow);
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, true, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow, 0, sf);
         else
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, true, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow);
+            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, true, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow, 0, sf);
     }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad_signsgd");
     return SPHIP_OK;
+}
+
+extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                                   int coeff_dtype, const void* rows, int rows_dtype,
+                                                   const float* row_shift, int64_t N, int64_t k, int64_t M, int64_t D,
+                                                   float* param, float lr, void* bf16_shadow, void* workspace,
+                                                   size_t workspace_bytes, void* stream) {
+    return fused_weight_grad_step(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, row_shift, N, k, M, D, param, lr,
+                                  bf16_shadow, workspace, workspace_bytes, stream, sphip::SfArgs{nullptr, 0.f, 0.f, 0.f});
+}
+
+extern "C" int sphip_segmented_weight_grad_schedulefree(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                                        int coeff_dtype, const void* rows, int rows_dtype,
+                                                        const float* row_shift, int64_t N, int64_t k, int64_t M,
+                                                        int64_t D, float* param, float* z, float lr, float beta, float c,
+                                                        void* bf16_shadow, void* workspace, size_t workspace_bytes,
+                                                        void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(z != nullptr && ((uintptr_t)z & 15) == 0, SPHIP_EINVAL,
+                  "segmented_weight_grad_schedulefree: z must be a 16-byte aligned buffer");
+    SPHIP_REQUIRE(beta > 0.f && beta <= 1.f, SPHIP_EINVAL, "segmented_weight_grad_schedulefree: bad beta");
+    return fused_weight_grad_step(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, row_shift, N, k, M, D, param, lr,
+                                  bf16_shadow, workspace, workspace_bytes, stream, SfArgs{z, 1.f - 1.f / beta, c, 1.f - beta});
 }
 
 // table (M, D) fp32 row-major -> [D/32][M][32 floats]: one contiguous M x 128 B block per column

@@ -103,8 +103,9 @@ def shadow_is_current(t: Tensor) -> bool:
     return hit is not None and hit[1] == (t._version, tuple(t.shape))
 
 
-# Optimizer-in-backward for the encoder matrix (sign_sgd.SignSGD.fuse_encoder_update): the
-# optimizer registers a Parameter with a callable returning its learning rate. For a registered
+# Optimizer-in-backward for the encoder matrix (sign_sgd.SignSGD.fuse_encoder_update,
+# schedule_free.ScheduleFreeWrapper.fuse_encoder_update): the optimizer registers a Parameter with
+# a callable returning its learning rate (or, schedule-free, lr + z + beta + the step's c). For a registered
 # weight the backward applies p -= lr * sign(grad) inside the gradient kernel and returns no
 # gradient. Keyed by storage address, validated through a weak reference to the Parameter, so
 # an entry can never outlive its parameter and match another tensor at the same address.
@@ -271,7 +272,12 @@ class FusedEncoder(torch.autograd.Function):
         if fuse:
             # every reader of the old weight in this backward has been enqueued: update in place
             shadow = peek_bf16_shadow(weight)
-            ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, lr_of(), shadow, row_shift=shift)
+            how = lr_of()                    # lr, or {"lr", "z", "beta", "c"} for the schedule-free wrapper
+            if isinstance(how, dict):
+                ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how["lr"], shadow, row_shift=shift,
+                                                   schedule_free=(how["z"], how["beta"], how["c"]))
+            else:
+                ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how, shadow, row_shift=shift)
             torch.autograd.graph.increment_version(weight)
             if shadow is not None:
                 register_bf16_shadow(weight, shadow)

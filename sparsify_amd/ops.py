@@ -406,9 +406,12 @@ def segment_coeff_sums(seg: LatentSegments, coeff: Tensor) -> Tensor:
 
 
 def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Tensor, param: Tensor, lr: float,
-                                   bf16_shadow: Tensor | None = None, row_shift: Tensor | None = None) -> Tensor:
+                                   bf16_shadow: Tensor | None = None, row_shift: Tensor | None = None,
+                                   schedule_free: tuple | None = None) -> Tensor:
     """param -= lr * sign(weight gradient) without materialising the gradient (fused_encoder.py:67-77
-    + sign_sgd.py:23); the same arithmetic as segmented_weight_grad followed by signsgd_step_."""
+    + sign_sgd.py:23); the same arithmetic as segmented_weight_grad followed by signsgd_step_.
+    schedule_free = (z, beta, c): the schedule-free step of (param = y, z) instead
+    (schedulefree_signsgd_step_)."""
     _req(coeff, "coeff", ndim=2)
     _req(rows, "rows", ndim=2)
     _req(param, "param", torch.float32, 2)
@@ -427,10 +430,20 @@ def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Ten
     lib = _lib.load()
     ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
     _ev = timer.start("sphip_segmented_weight_grad_signsgd", rows)
-    check(lib.sphip_segmented_weight_grad_signsgd(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff),
-                                                  rows.data_ptr(), _dt(rows), _ptr(row_shift), N, k, M, D, param.data_ptr(),
-                                                  float(lr), _ptr(bf16_shadow), ws.data_ptr(), ws.numel(), _stream(rows)),
-          "sphip_segmented_weight_grad_signsgd")
+    if schedule_free is None:
+        check(lib.sphip_segmented_weight_grad_signsgd(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
+                                                      _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(row_shift), N, k, M, D,
+                                                      param.data_ptr(), float(lr), _ptr(bf16_shadow), ws.data_ptr(),
+                                                      ws.numel(), _stream(rows)), "sphip_segmented_weight_grad_signsgd")
+    else:
+        z, beta, c = schedule_free
+        _req(z, "z", torch.float32, 2)
+        if z.shape != param.shape:
+            raise ValueError("segmented_weight_grad_signsgd: z shape mismatch")
+        check(lib.sphip_segmented_weight_grad_schedulefree(
+            seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff), rows.data_ptr(), _dt(rows),
+            _ptr(row_shift), N, k, M, D, param.data_ptr(), z.data_ptr(), float(lr), float(beta), float(c),
+            _ptr(bf16_shadow), ws.data_ptr(), ws.numel(), _stream(rows)), "sphip_segmented_weight_grad_schedulefree")
     timer.stop(_ev, rows)
     return param
 

@@ -85,6 +85,41 @@ class ScheduleFreeWrapper:
         f = getattr(self.base, "reduces", None)
         return bool(f and f(p))
 
+    def _peek_weights(self, group) -> float:
+        """The c the NEXT step() of this group will use, without advancing its state."""
+        lr = group["lr"] * group.get("d", 1.0)
+        lr_max = max(lr, group["lr_max"])
+        weight = ((group["k"] + 1) ** self.r) * (lr_max ** self.weight_lr_power)
+        total = group["weight_sum"] + weight
+        return weight / total if total > 0 else 0.0
+
+    def fuse_encoder_update(self, weights) -> None:
+        """Optimizer-in-backward for encoder matrices, as SignSGD.fuse_encoder_update: FusedEncoder's
+        backward applies THIS wrapper's step to (p = y, z) inside the weight-gradient kernel and
+        leaves p.grad None, so step() only advances the group's weights for them. Same validity
+        conditions (one rank, one backward per optimizer step, nothing else reads that gradient)."""
+        from .fused_encoder import register_inplace_signsgd
+        from .sign_sgd import SignSGD
+        if not isinstance(self.base, SignSGD):
+            raise TypeError("fuse_encoder_update needs the SignSGD base optimizer")
+        for group in self.param_groups:
+            for p in group["params"]:
+                if any(p is w for w in weights):
+                    if group.get("project_rows", False):
+                        raise ValueError("decoder matrices need the projected gradient: not fusable")
+
+                    def how(p=p):
+                        if not self.train_mode:
+                            raise RuntimeError("call .train() on the schedule-free optimizer before stepping")
+                        # (looked up per call: load_state_dict replaces the group dictionaries)
+                        g = next(gr for gr in self.param_groups if any(q is p for q in gr["params"]))
+                        st = self.state[p]
+                        if "z" not in st:
+                            st["z"] = p.detach().clone(memory_format=torch.preserve_format)
+                        return {"lr": g["lr"], "z": st["z"], "beta": self.momentum, "c": self._peek_weights(g)}
+
+                    register_inplace_signsgd(p, how)
+
     def _weights(self, group) -> float:
         lr = group["lr"] * group.get("d", 1.0)
         group["lr_max"] = max(lr, group["lr_max"])

@@ -80,7 +80,9 @@ class SignSGD(Optimizer):
                 if any(p is w for w in weights):
                     if group.get("project_rows", False):
                         raise ValueError("decoder matrices need the projected gradient: not fusable")
-                    register_inplace_signsgd(p, lambda g=group: g["lr"])
+                    # (the group is looked up per call: load_state_dict replaces the group dictionaries)
+                    register_inplace_signsgd(p, lambda p=p: next(
+                        gr for gr in self.param_groups if any(q is p for q in gr["params"]))["lr"])
 
     def unfuse_encoder_update(self) -> None:
         from .fused_encoder import unregister_inplace_signsgd

@@ -174,6 +174,12 @@ class Trainer:
                                               momentum=0.95)
                     opt.train()
                     self.optimizers = [opt]
+                    one_rank = not (dist.is_initialized() and dist.get_world_size() > 1)
+                    if (cfg.fuse_encoder_update and (one_rank or cfg.distribute_modules) and not cfg.shard_latents
+                            and cfg.grad_acc_steps * cfg.micro_acc_steps == 1 and cfg.loss_fn == "fvu"
+                            and self.device.type == "cuda"):
+                        opt.fuse_encoder_update([sae.encoder.weight for sae in self.saes.values()
+                                                 if not opt.reduces(sae.encoder.weight)])
                 else:
                     opt = SignSGD(pgs, exchange_signs=exchange, overlap=cfg.overlap_exchange)
                     self.optimizers = [opt]

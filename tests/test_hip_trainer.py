@@ -145,6 +145,48 @@ def test_fused_encoder_update_equals_separate_step(device, transcode, dtype, mon
     assert res[False][1] == res[True][1]
 
 
+@pytest.mark.parametrize("transcode", [False, True])
+def test_fused_encoder_update_schedulefree_equals_separate_step(device, transcode, monkeypatch):
+    """The same for the reference's default optimizer "signum" (schedule-free SignSGD): the step of
+    (encoder.weight = y, z) applied inside the weight-gradient kernel leaves bit for bit the
+    parameters, the z buffers and the averaged weights of gradient + one-kernel optimizer step."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig, ops
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N, steps = 128, 2048, 16, 1024, 6
+    batches = make_batches(steps, N, D, transcode)
+    gpu = [tuple(t.cuda().bfloat16() for t in b) if transcode else b.cuda().bfloat16() for b in batches]
+    calls = {"fused": 0}
+    fused_op = ops.segmented_weight_grad_signsgd_
+
+    def count_fused(*a, **kw):
+        calls["fused"] += kw.get("schedule_free") is not None
+        return fused_op(*a, **kw)
+
+    monkeypatch.setattr(ops, "segmented_weight_grad_signsgd_", count_fused)
+    res = {}
+    for fuse in (False, True):
+        cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, transcode=transcode), optimizer="signum",
+                          save_dir="", save_every=10**9, wandb_log_frequency=1, fuse_encoder_update=fuse)
+        torch.manual_seed(0)
+        tr = Trainer(cfg, ListSource(gpu, D), device="cuda")
+        calls["fused"] = 0
+        fvus = []
+        for b in gpu:
+            tr.train_micro_batch({"h0": b})
+            fvus.append(tr.last_logged["fvu/h0"])
+        assert calls["fused"] == (steps if fuse else 0)
+        opt, sae = tr.optimizers[0], tr.saes["h0"]
+        y = {n: p.detach().clone() for n, p in sae.named_parameters()}
+        z = {n: opt.state[p]["z"].clone() for n, p in sae.named_parameters()}
+        opt.eval()
+        x = {n: p.detach().clone() for n, p in sae.named_parameters()}
+        res[fuse] = (y, z, x, fvus, [g["k"] for g in opt.param_groups])
+    for part in range(3):
+        for name, ref in res[False][part].items():
+            assert torch.equal(ref, res[True][part][name]), (part, name)
+    assert res[False][3] == res[True][3] and res[False][4] == res[True][4] == [steps] * len(res[True][4])
+
+
 def test_trainer_save_best(device, tmp_path):
     """trainer.py:540-544, 701-724: at every save_every-th step the per-coder best FVU is
     tracked and the coder written under {run}/best/{name}; a worse loss overwrites nothing."""
