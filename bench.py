@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal with --gpus 1: run the data-parallel gradient exchange over a one-rank group")
     ap.add_argument("--no-overlap", action="store_true", help="gradient exchange on the compute stream (A/B)")
+    ap.add_argument("--lazy-pre-acts", action="store_true",
+                    help="TrainConfig.lazy_pre_acts: top-k from candidate lists, the (N, M) matrix is not stored (A/B)")
     ap.add_argument("--mode", default="ddp", choices=["ddp", "shard"],
                     help="ddp: replicas, tokens split over the ranks (weak scaling, the headline); shard: the latents of "
                          "one dictionary split over the ranks, every rank sees the same tokens (strong scaling)")
@@ -186,7 +188,7 @@ def main():
     cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, transcode=bool(w.get("transcode"))), shard_latents=shard,
                       optimizer=args.optimizer, hookpoints=["layers.10"],
                       save_every=10**9, wandb_log_frequency=10**9, save_dir="", log_to_wandb=False,
-                      overlap_exchange=not args.no_overlap)
+                      overlap_exchange=not args.no_overlap, lazy_pre_acts=args.lazy_pre_acts)
     total = args.warmup + args.steps
     src = SyntheticActivations(["layers.10"], D, N, total, device=device,
                                dtype=torch.float32 if args.fp32 else torch.bfloat16, rank=0 if shard else rank,
@@ -235,7 +237,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         # one launch per step, or one per latent block when the forward follows an overlapped
         # gradient exchange (N > 1): the roofline figure is per step either way
-        gemm_ms = sum(kern[n]["total_ms"] for n in ("sphip_encoder_preacts", "sphip_encoder_preacts_block")
+        gemm_ms = sum(kern[n]["total_ms"] for n in ("sphip_encoder_preacts", "sphip_encoder_preacts_block",
+                                                    "sphip_encoder_preacts_emit")
                       if n in kern) / args.steps
         flops = 2.0 * N * D * M / (world if shard else 1)        # algorithmic FLOP per step and rank
         tflops = flops / (gemm_ms * 1e-3) / 1e12
@@ -288,7 +291,7 @@ def main():
             "dtype": "f32" if args.fp32 else "bf16",
             "data": "synthetic",
             "config": {"workload": args.workload, "tokens_per_gpu_per_step": N, "optimizer": args.optimizer,
-                       "params": "fp32", "parallelism": f"latent-shard{world}" if shard else f"dp{world}", "mean_fvu": fvu},
+                       "params": "fp32", "lazy_pre_acts": bool(args.lazy_pre_acts), "parallelism": f"latent-shard{world}" if shard else f"dp{world}", "mean_fvu": fvu},
             "roofline": roof,
             "kernels_ms_per_step": {n: v["total_ms"] / args.steps for n, v in kern.items()},
             "byte_bound_kernels": byte_kernels,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SPHIP_ABI_VERSION 1
+#define SPHIP_ABI_VERSION 2
 
 enum { SPHIP_F32 = 0, SPHIP_BF16 = 1 };
 enum { SPHIP_OK = 0, SPHIP_EINVAL = 1, SPHIP_EUNSUPPORTED = 2, SPHIP_ELAUNCH = 3, SPHIP_EWORKSPACE = 4 };
@@ -94,6 +94,40 @@ int sphip_encoder_preacts_block(const void* x, const void* W, const void* bias, 
  * reaches the k-th largest block maximum are read; the result is identical either way. */
 int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max,
                int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx, void* stream);
+
+/* ---- top-k without the (N, M) matrix (fused_encoder.py:29-33 when nobody reads pre_acts;
+ * the reference always materialises it, fused_encoder.py:50, and only AuxK / multi-top-k read it,
+ * sparse_coder.py:230-262). bf16, relu, k <= 256, D % 64 == 0. Sequence for one batch, all on
+ * one stream (csrc/lazy.hip has the argument for exactness):
+ *   1. sphip_encoder_preacts + sphip_topk over the first M_a latents (any split with
+ *      M_a % 256 == 0, M_a >= k; about M/4)            -> vals_a, idx_a
+ *   2. sphip_row_min(vals_a)                            -> tau (N) bf16 bits
+ *   3. sphip_encoder_preacts_emit over latents [M_a, M): nothing of the product is stored but
+ *      the 16-byte chunks (8 latents) holding a value above the token's tau, appended to the
+ *      token's list in the workspace (capacity `cap` chunks per token, cap <= 4096); reset != 0
+ *      clears the counters and the flag first (0: a further block of the same batch)
+ *   4. sphip_topk_candidates -> vals, idx: the same set as sphip_topk over the whole row,
+ *      value-descending, ties to the lowest index
+ *   5. the first int32 of the workspace is a flag, raised when a token's list or the sort
+ *      buffer (1024 entries at or above the k-th value) overflowed; rows may then be wrong.
+ *      sphip_encoder_preacts_if + sphip_topk_if enqueued behind with run_if = that word redo
+ *      the ordinary path over all rows when it is up and return at once when it is not
+ *      (bf16, D % 64 == 0, M % 8 == 0; same arguments as the unpredicated calls otherwise).
+ * Workspace: sphip_lazy_workspace_bytes(N, cap), 256-byte aligned. */
+size_t sphip_lazy_workspace_bytes(int64_t N, int64_t cap);   /* 0: cap out of [1, 4096] */
+int sphip_row_min(const void* vals, int64_t N, int64_t k, void* out, void* stream);
+int sphip_encoder_preacts_emit(const void* x, const void* W, const void* bias, int64_t N, int64_t D,
+                               int64_t M_block, int64_t first_latent, const void* tau, int64_t cap,
+                               int reset, void* ws, int64_t ws_bytes, void* stream);
+int sphip_topk_candidates(const void* vals_a, const int64_t* idx_a, const void* tau, int64_t N,
+                          int64_t k, int64_t cap, void* ws, int64_t ws_bytes, void* vals,
+                          int64_t* idx, void* stream);
+int sphip_encoder_preacts_if(const int* run_if, const void* x, const void* W, const void* bias,
+                             void* pre, void* tile_max, int64_t N, int64_t D, int64_t M, int relu,
+                             void* stream);
+int sphip_topk_if(const int* run_if, const void* pre, int dtype, const uint8_t* keep_mask,
+                  const void* tile_max, int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx,
+                  void* stream);
 
 /* groupmax, fused_encoder.py:34-43: max over k contiguous groups of M/k latents. M % k == 0. */
 int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, void* vals,

@@ -12,7 +12,7 @@ from pathlib import Path
 
 LIB_NAME = "libsparsify_hip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16 = 0, 1
 
@@ -34,6 +34,12 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_encoder_preacts_block": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _P]),
     "sphip_topk": (_I, [_P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_groupmax": (_I, [_P, _I, _L, _L, _L, _P, _P, _P]),
+    "sphip_lazy_workspace_bytes": (_Z, [_L, _L]),
+    "sphip_row_min": (_I, [_P, _L, _L, _P, _P]),
+    "sphip_encoder_preacts_emit": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _L, _I, _P, _L, _P]),
+    "sphip_topk_candidates": (_I, [_P, _P, _P, _L, _L, _L, _P, _L, _P, _P, _P]),
+    "sphip_encoder_preacts_if": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P]),
+    "sphip_topk_if": (_I, [_P, _P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_gather_rows_weighted": (_I, [_P, _P, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
     "sphip_gather_l2_workspace_bytes": (_Z, [_L, _L, _L, _L]),
     "sphip_gather_rows_weighted_l2": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P]),

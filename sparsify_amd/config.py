@@ -83,6 +83,11 @@ class TrainConfig(_Serializable):
     """(not in the reference) "signsgd" on one rank without gradient accumulation: apply the step of
     `encoder.weight` inside its gradient kernel (same update; the (M, D) gradient is never
     materialised, so `encoder.weight.grad` stays None)."""
+    lazy_pre_acts: bool = False
+    """(not in the reference) forward passes whose pre-activations nobody reads (no AuxK, no
+    multi-top-k) do not store the (tokens, latents) matrix: top-k from candidate lists the GEMM
+    epilogue emits (csrc/lazy.hip). Same selection; 4 GiB less per 16384 tokens, about 3 % more
+    forward time at the headline shape."""
     save_every: int = 1000
     save_best: bool = False
     finetune: str | None = None

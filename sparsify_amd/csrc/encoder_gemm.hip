@@ -251,7 +251,7 @@ static int launch_gemm(const void* x, const void* W, const void* bias, void* pre
 
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
                          int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s,
-                         int* status);   // encoder_gemm256.hip
+                         int* status, const int* run_if = nullptr);   // encoder_gemm256.hip
 
 int launch_gemm256_axpy(const void* x, const void* W, const void* C, void* out, int64_t N, int64_t K, int64_t M,
                         int64_t ld_c, int64_t ld_out, float alpha, float beta, hipStream_t s);   // encoder_gemm256.hip
@@ -346,6 +346,23 @@ extern "C" int sphip_encoder_preacts_block(const void* x, const void* W, const v
                             &status))
         return status;
     set_error("encoder_preacts_block: D=%lld is not a multiple of 64", (long long)D);
+    return SPHIP_EUNSUPPORTED;
+}
+
+extern "C" int sphip_encoder_preacts_if(const int* run_if, const void* x, const void* W, const void* bias, void* pre,
+                                        void* tile_max, int64_t N, int64_t D, int64_t M, int relu, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(run_if && x && W && pre, SPHIP_EINVAL, "encoder_preacts_if: null pointer");
+    SPHIP_REQUIRE(N > 0 && D > 0 && M > 0 && N < (1ll << 31) && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL,
+                  "encoder_preacts_if: bad shape N=%lld D=%lld M=%lld", (long long)N, (long long)D, (long long)M);
+    SPHIP_REQUIRE(M % 8 == 0, SPHIP_EUNSUPPORTED, "encoder_preacts_if: M=%lld must be a multiple of 8", (long long)M);
+    SPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)pre & 15) == 0 &&
+                      ((uintptr_t)run_if & 3) == 0, SPHIP_EINVAL, "encoder_preacts_if: operands must be 16-byte aligned");
+    int status = SPHIP_OK;
+    if (launch_gemm256_bf16(x, W, bias, pre, tile_max, N, D, M, M, cdiv(M, 128), relu, (hipStream_t)stream, &status,
+                            run_if))
+        return status;
+    set_error("encoder_preacts_if: D=%lld is not a multiple of 64", (long long)D);
     return SPHIP_EUNSUPPORTED;
 }
 

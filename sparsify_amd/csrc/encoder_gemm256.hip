@@ -61,23 +61,48 @@ __device__ __forceinline__ void seg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Candidate emission (OUTF 4, sphip_encoder_preacts_emit) and the predicated launch
+// (sphip_encoder_preacts_if): see the epilogue below and lazy.hip.
+struct EmitArgs {
+    const unsigned short* tau = nullptr;   // per token: bits of the bf16 threshold (a relu output, >= +0)
+    unsigned* cnt = nullptr;               // per token: chunks appended so far
+    u32x4_t* list = nullptr;               // [N][cap] chunks of 8 consecutive bf16 pre-activations
+    unsigned* ids = nullptr;               // [N][cap] index of a chunk's first latent / 8
+    int* flag = nullptr;                   // raised when a token's list overflows
+    const int* run_if = nullptr;           // predicated launch: every workgroup leaves when *run_if == 0
+    int cap = 0;
+    unsigned id_base = 0;                  // (first latent of this launch's block) / 8
+    int diag = 0;                          // SPHIP_EMIT_DIAG (timing experiments): 1 no atomics, 2 no stores, 4 no pass 1
+};
+
 // OUTF: 0 = the encoder's epilogue (bias, ReLU, bf16, block maxima); 1 = store the fp32
 // accumulators as they are (P is float*); 2 = add them to the fp32 values already in P
 // (sphip_gemm_bf16_f32acc: products whose fp32 operand was split into bf16 terms);
 // 3 = bf16 P = rnd(rnd(alpha * rnd(acc)) + rnd(beta * C)) with C = `bias` (row stride tilesT, may
-// be null), the Newton-Schulz products of Muon (sphip_gemm_bf16_axpy, encoder_gemm.hip).
+// be null), the Newton-Schulz products of Muon (sphip_gemm_bf16_axpy, encoder_gemm.hip);
+// 4 = the encoder's values are not stored: every 16-byte chunk (8 latents) of a token that holds a
+// value above the token's threshold is appended to the token's candidate list.
 template <bool RELU, int DIAG, int OUTF>
 __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                              const bf16_t* __restrict__ bias, bf16_t* __restrict__ P, int N, int D,
                                              int M, int tm, int tn, bf16_t* __restrict__ tile_max, int64_t ldp,
                                              int tilesT, unsigned* dbg, char* smem, float alpha = 1.f,
-                                             float beta = 0.f) {
+                                             float beta = 0.f, const EmitArgs& ea = EmitArgs()) {
     const int m0 = (DIAG & 16) ? (tm & 1) * G_TILE : tm * G_TILE, n0 = (DIAG & 16) ? (tn & 1) * G_TILE : tn * G_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    // OUTF 4: lane L holds the threshold of the wave's token L as T = (t | 0x8000) in both
+    // halves of a dword: for two packed non-negative bf16 values w, bits 15 / 31 of T - w are
+    // clear exactly where a value exceeds t. Tokens past N get a threshold nothing exceeds.
+    unsigned tau_T = 0xFFFFFFFFu;
+    if (OUTF == 4) {
+        const int n = n0 + wn * 64 + lane;
+        const unsigned t = n < N ? (unsigned)ea.tau[n] : 0x7FFFu;
+        tau_T = (t | 0x8000u) * 0x10001u;
+    }
     const int r16 = lane & 15, q4 = lane >> 4;
     const int kTiles = D / G_BK;
 
@@ -306,7 +331,7 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
         }
         return;
     }
-    if (OUTF != 0) {
+    if (OUTF == 1 || OUTF == 2) {
         // fp32 output: the lane's 4 consecutive columns of one row per accumulator tile, 16-B
         // pieces straight from the registers (these products write N x M / K-fold fewer bytes
         // than they read, the store shape does not matter)
@@ -375,6 +400,61 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
     if (DIAG & 8) return;
     const int chunk = lane & 15;
     const int mcol = m0 + wm * 128 + chunk * 8;
+    if (OUTF == 4) {
+        // The 16-byte pad behind a token's 256 staged bytes holds {T, chunks hit, list position}.
+        // Pass 1 marks the chunks holding a value above the threshold (one ballot per four
+        // tokens, kept in scalar registers) and counts them per token; lane L then reserves
+        // token L's share of its list with one returning atomic; pass 2 stores the marked chunks.
+        *reinterpret_cast<unsigned*>(epi + lane * EPI_ROW + 256) = tau_T;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long hm[16];
+        if (ea.diag & 4) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tok = i * 4 + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(epi + tok * EPI_ROW + chunk * 16);
+            const unsigned T = *reinterpret_cast<const unsigned*>(epi + tok * EPI_ROW + 256);
+            const unsigned below = (T - v.x) & (T - v.y) & (T - v.z) & (T - v.w) & 0x80008000u;
+            hm[i] = __ballot(below != 0x80008000u);
+            const unsigned grp = (unsigned)(hm[i] >> ((lane >> 4) * 16)) & 0xffffu;
+            if (chunk == 0) *reinterpret_cast<unsigned*>(epi + tok * EPI_ROW + 260) = (unsigned)__popc(grp);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const unsigned mine = *reinterpret_cast<const unsigned*>(epi + lane * EPI_ROW + 260);
+            const int n = n0 + wn * 64 + lane;
+            unsigned base = 0;
+            if (mine != 0 && n < N && !(ea.diag & 1)) {
+                base = __hip_atomic_fetch_add(ea.cnt + n, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (base + mine > (unsigned)ea.cap) *ea.flag = 1;
+            }
+            *reinterpret_cast<unsigned*>(epi + lane * EPI_ROW + 264) = base;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (hm[i] == 0ull) continue;                             // wave-uniform
+            const int tok = i * 4 + (lane >> 4);
+            const int n = n0 + wn * 64 + tok;
+            const unsigned grp = (unsigned)(hm[i] >> ((lane >> 4) * 16)) & 0xffffu;
+            if (((grp >> chunk) & 1u) == 0u || n >= N) continue;
+            const unsigned pos = *reinterpret_cast<const unsigned*>(epi + tok * EPI_ROW + 264) +
+                                 (unsigned)__popc(grp & ((1u << chunk) - 1u));
+            if (pos >= (unsigned)ea.cap || (ea.diag & 2)) continue;  // overflow: the flag is up
+            const uint4 v = *reinterpret_cast<const uint4*>(epi + tok * EPI_ROW + chunk * 16);
+            const int64_t at = (int64_t)n * ea.cap + pos;
+            const u32x4_t nv = {v.x, v.y, v.z, v.w};
+            ea.list[at] = nv;
+            ea.ids[at] = ea.id_base + (unsigned)(mcol >> 3);
+        }
+        return;
+    }
     // ldp: row stride of P; tilesT: row length of tile_max (both those of the whole matrix when
     // this launch computes a block of latents, sphip_encoder_preacts_block)
     const bool vec = (M & 7) == 0 && (ldp & 7) == 0;
@@ -437,8 +517,9 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
                                                                  int tilesM, int tilesN, bf16_t* __restrict__ tile_max,
                                                                  int64_t ldp, int tilesT, int bandh,
                                                                  unsigned* dbg = nullptr, float alpha = 1.f,
-                                                                 float beta = 0.f) {
+                                                                 float beta = 0.f, EmitArgs ea = EmitArgs()) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ea.run_if != nullptr && *ea.run_if == 0) return;
     const unsigned nb = (unsigned)tilesM * (unsigned)tilesN;
     for (unsigned vb = blockIdx.x; vb < nb; vb += gridDim.x) {
         // ---- tile coordinates (XCD-contiguous ranges, 8-tall bands; see encoder_gemm.hip)
@@ -450,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         const unsigned first = g * (unsigned)bandh;
         const unsigned gsize = min((unsigned)tilesM - first, (unsigned)bandh);
         gemm256_tile<RELU, DIAG, OUTF>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
-                                       tile_max, ldp, tilesT, dbg, smem, alpha, beta);
+                                       tile_max, ldp, tilesT, dbg, smem, alpha, beta, ea);
         if (vb + gridDim.x < nb) __syncthreads();      // the next tile's staging overwrites the epilogue area
     }
 }
@@ -475,7 +556,8 @@ static int gemm_band() {
 // Host launcher, called from sphip_encoder_preacts (encoder_gemm.hip). Returns false when the
 // shape is not eligible (caller falls back to the 128x128 kernel).
 bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* pre, void* tile_max, int64_t N,
-                         int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s, int* status) {
+                         int64_t D, int64_t M, int64_t ldp, int64_t tilesT, int relu, hipStream_t s, int* status,
+                         const int* run_if) {
     if (D % G_BK != 0 || D < G_BK) return false;
     const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
     const int64_t nblocks = (int64_t)tilesM * tilesN;
@@ -491,7 +573,10 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
     }
     // SPHIP_GEMM_PERSIST=n: n resident workgroups per CU-count of 256 walk the tiles (A/B switch)
     const char* pers = getenv("SPHIP_GEMM_PERSIST");
-    const int64_t resident = pers ? 256ll * atoi(pers) : 0;
+    // a predicated launch is resident: when the predicate is down its 512 workgroups leave at once
+    const int64_t resident = run_if ? 512 : (pers ? 256ll * atoi(pers) : 0);
+    EmitArgs ea;
+    ea.run_if = run_if;
     dim3 grid((unsigned)((resident > 0 && resident < nblocks) ? resident : nblocks)), block(512);
 #ifdef SPHIP_DIAG
     const char* dg = getenv("SPHIP_GEMM_DIAG");
@@ -531,10 +616,12 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
 #endif
     if (relu)
         hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band());
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(),
+                           (unsigned*)nullptr, 1.f, 0.f, ea);
     else
         hipLaunchKernelGGL((encoder_gemm256_kernel<false>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band());
+                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(),
+                           (unsigned*)nullptr, 1.f, 0.f, ea);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("encoder_preacts(256): launch failed: %s", hipGetErrorString(e));
@@ -587,6 +674,40 @@ int launch_gemm256_axpy(const void* x, const void* W, const void* C, void* out, 
                        (const bf16_t*)W, (const bf16_t*)C, (bf16_t*)out, (int)N, (int)K, (int)M, tilesM, tilesN,
                        (bf16_t*)nullptr, ld_out, (int)ld_c, gemm_band(), (unsigned*)nullptr, alpha, beta);
     SPHIP_CHECK_LAUNCH("gemm_bf16_axpy");
+    return SPHIP_OK;
+}
+
+// relu(x W^T + b) in bf16, not stored: chunks holding a value above the token's threshold are
+// appended to the token's candidate list (OUTF 4 above). W holds the M rows of a latent block
+// whose first latent is 8 * id_base.
+int launch_gemm256_emit(const void* x, const void* W, const void* bias, int64_t N, int64_t D, int64_t M,
+                        const void* tau, unsigned* cnt, void* list, unsigned* ids, int* flag, int64_t cap,
+                        int64_t id_base, hipStream_t s) {
+    const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SPHIP_REQUIRE(hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, 0, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES) == hipSuccess,
+                      SPHIP_ELAUNCH, "encoder_preacts_emit: cannot reserve %d bytes of LDS", G_LDS_BYTES);
+        attr_set = true;
+    }
+    EmitArgs ea;
+    ea.tau = (const unsigned short*)tau;
+    ea.cnt = cnt;
+    ea.list = (u32x4_t*)list;
+    ea.ids = ids;
+    ea.flag = flag;
+    ea.cap = (int)cap;
+    ea.id_base = (unsigned)id_base;
+    {
+        const char* dg = getenv("SPHIP_EMIT_DIAG");
+        ea.diag = dg ? atoi(dg) : 0;
+    }
+    dim3 grid((unsigned)((int64_t)tilesM * tilesN)), block(512);
+    hipLaunchKernelGGL((encoder_gemm256_kernel<true, 0, 4>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
+                       (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)nullptr, (int)N, (int)D, (int)M, tilesM, tilesN,
+                       (bf16_t*)nullptr, (int64_t)0, 0, gemm_band(), (unsigned*)nullptr, 1.f, 0.f, ea);
+    SPHIP_CHECK_LAUNCH("encoder_preacts_emit");
     return SPHIP_OK;
 }
 

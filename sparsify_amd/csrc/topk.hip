@@ -86,7 +86,9 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
                                                           const uint8_t* __restrict__ keep,
                                                           const T* __restrict__ tile_max, int M,
                                                           int k, T* __restrict__ vals,
-                                                          int64_t* __restrict__ idx_out) {
+                                                          int64_t* __restrict__ idx_out,
+                                                          const int* __restrict__ run_if = nullptr) {
+    if (run_if != nullptr && *run_if == 0) return;     // predicated launch (sphip_topk_if)
     constexpr int TK_WAVES = TK_THREADS / 64;
     constexpr int V = KeyOf<T>::VEC;
     constexpr int BITS = KeyOf<T>::BITS;
@@ -371,9 +373,27 @@ __global__ __launch_bounds__(256) void groupmax_kernel(const T* __restrict__ pre
 
 }  // namespace sphip
 
+namespace sphip {
+static int topk_impl(const int* run_if, const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max,
+                     int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx, void* stream);
+}
+
 extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max, int64_t N,
                           int64_t M, int64_t k, void* vals, int64_t* idx, void* stream) {
+    return sphip::topk_impl(nullptr, pre, dtype, keep_mask, tile_max, N, M, k, vals, idx, stream);
+}
+
+extern "C" int sphip_topk_if(const int* run_if, const void* pre, int dtype, const uint8_t* keep_mask,
+                             const void* tile_max, int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx,
+                             void* stream) {
     using namespace sphip;
+    SPHIP_REQUIRE(run_if != nullptr && ((uintptr_t)run_if & 3) == 0, SPHIP_EINVAL, "topk_if: null or unaligned predicate");
+    return topk_impl(run_if, pre, dtype, keep_mask, tile_max, N, M, k, vals, idx, stream);
+}
+
+static int sphip::topk_impl(const int* run_if, const void* pre, int dtype, const uint8_t* keep_mask,
+                            const void* tile_max, int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx,
+                            void* stream) {
     SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "topk: bad dtype %d", dtype);
     SPHIP_REQUIRE(pre && vals && idx, SPHIP_EINVAL, "topk: null pointer");
     SPHIP_REQUIRE(N > 0 && M > 0, SPHIP_EINVAL, "topk: empty shape N=%lld M=%lld", (long long)N, (long long)M);
@@ -393,19 +413,19 @@ extern "C" int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, 
     if (small) {
         dim3 sblock(TK_THREADS_S);
         if (dtype == SPHIP_BF16)
-            hipLaunchKernelGGL((topk_kernel<bf16_t, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<bf16_t, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx, run_if);
         else
-            hipLaunchKernelGGL((topk_kernel<float, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<float, true, TK_THREADS_S, TK_CAP_S>), grid, sblock, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx, run_if);
     } else if (dtype == SPHIP_BF16) {
         if (aligned)
-            hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx, run_if);
         else
-            hipLaunchKernelGGL((topk_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)pre, keep_mask, (const bf16_t*)tile_max, (int)M, (int)k, (bf16_t*)vals, idx, run_if);
     } else {
         if (aligned)
-            hipLaunchKernelGGL((topk_kernel<float, true>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<float, true>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx, run_if);
         else
-            hipLaunchKernelGGL((topk_kernel<float, false>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx);
+            hipLaunchKernelGGL((topk_kernel<float, false>), grid, block, 0, s, (const float*)pre, keep_mask, (const float*)tile_max, (int)M, (int)k, (float*)vals, idx, run_if);
     }
     SPHIP_CHECK_LAUNCH("topk");
     return SPHIP_OK;

@@ -10,6 +10,7 @@ Backward: only the k selected columns -- segmented (latent-major) weight/bias gr
 """
 from __future__ import annotations
 
+import os
 from typing import Literal, NamedTuple
 
 import torch
@@ -30,6 +31,76 @@ class EncoderOutput(NamedTuple):
 
 
 import weakref
+
+# Opt-in (SPHIP_LAZY_PREACTS=1, TrainConfig.lazy_pre_acts, or set this attribute): on eligible
+# shapes the forward does not store the (N, M) pre-activations; EncoderOutput.pre_acts is then a
+# LazyPreActs that recomputes them on first use. Measured at the headline shape
+# (benchmarks/lazy_bench.py): 12.6 ms against 12.25 ms for GEMM + top-k -- the GEMM is bound by
+# the matrix pipe, not by its 4 GiB of stores, so what this buys is memory (4 GiB per 16384
+# tokens, 3 GiB of HBM writes and 1 GB of reads per step), not time. Hence off by default.
+LAZY_PRE_ACTS = os.environ.get("SPHIP_LAZY_PREACTS", "0") == "1"
+
+
+class LazyPreActs:
+    """Stand-in for EncoderOutput.pre_acts (fused_encoder.py:50) when the forward did not store
+    the matrix: shape / dtype / device answer at once; any other use -- a torch function, an
+    attribute, indexing -- first recomputes relu(x W^T + b) with the ordinary kernel, from the
+    operands of the forward. Reading it after the encoder weights changed raises."""
+
+    def __init__(self, x_low: Tensor, weight: Tensor, bias: Tensor | None, lead: tuple):
+        self._x, self._weight, self._bias, self._lead = x_low, weight, bias, tuple(lead)
+        self._version = (weight._version, None if bias is None else bias._version)
+        self._value: Tensor | None = None
+
+    @property
+    def shape(self):
+        return torch.Size((*self._lead, self._weight.shape[0]))
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    @property
+    def device(self):
+        return self._x.device
+
+    @property
+    def is_materialized(self) -> bool:
+        return self._value is not None
+
+    def materialize(self) -> Tensor:
+        if self._value is None:
+            now = (self._weight._version, None if self._bias is None else self._bias._version)
+            if now != self._version:
+                raise RuntimeError("pre_acts of a lazy EncoderOutput read after the encoder parameters changed; "
+                                   "read it before the optimizer step, or run with lazy pre_acts off")
+            pre = ops.encoder_preacts(self._x, bf16_shadow(self._weight),
+                                      None if self._bias is None else bf16_shadow(self._bias))
+            self._value = pre.reshape(*self._lead, pre.shape[-1])
+            self._x = None
+        return self._value
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(a):
+            if isinstance(a, LazyPreActs):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(unwrap(b) for b in a)
+            return a
+        return func(*unwrap(args), **{k_: unwrap(v) for k_, v in (kwargs or {}).items()})
+
 
 # address -> (weak reference to the owning tensor, (version, shape), bf16 buffer). The weak
 # reference pins an entry to the tensor it was made for: the caching allocator hands a freed
@@ -144,12 +215,15 @@ def low_precision_input(x2: Tensor, b_dec: Tensor | None) -> Tensor:
 
 class FusedEncoder(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, weight, bias, k: int, activation: Literal["groupmax", "topk"], b_dec=None):
+    def forward(ctx, input, weight, bias, k: int, activation: Literal["groupmax", "topk"], b_dec=None,
+                lazy_pre_acts: bool | None = None):
         """
         input:  (N, D)      weight: (M, D)      bias: (M,)
         k:      number of latents to keep per row
         b_dec:  optional (D,) decoder bias to subtract from the input first
                 (SparseCoder.encode, sparse_coder.py:191-192), fused here.
+        lazy_pre_acts: None = the module default LAZY_PRE_ACTS; False = always store pre_acts
+                (a caller that will read them: AuxK, multi-top-k).
         """
         if activation not in ("topk", "groupmax"):
             raise ValueError(f"Unknown activation: {activation}")
@@ -190,7 +264,14 @@ class FusedEncoder(torch.autograd.Function):
         if blocks and not (low and len(blocks) > 1 and shadow_is_current(weight) and x_low.shape[1] % 64 == 0):
             torch.cuda.current_stream(weight.device).wait_event(blocks[-1][2])
             blocks = None
-        if low and blocks:
+        lazy = LAZY_PRE_ACTS if lazy_pre_acts is None else lazy_pre_acts
+        lazy = (lazy and low and not blocks and activation == "topk"
+                and ops.lazy_eligible(x_low.shape[0], x_low.shape[1], weight.shape[0], k))
+        if lazy:
+            values, indices, _ = ops.encode_topk_lazy(
+                x_low, bf16_shadow(weight), None if bias is None else bf16_shadow(bias), k)
+            pre = LazyPreActs(x_low, weight, bias, lead)
+        elif low and blocks:
             N, M = x_low.shape[0], weight.shape[0]
             pre = torch.empty(N, M, dtype=torch.bfloat16, device=x_low.device)
             if activation == "topk":
@@ -212,7 +293,9 @@ class FusedEncoder(torch.autograd.Function):
             pre = ops.encoder_preacts(xf, weight.detach().contiguous(),
                                       None if bias is None else bias.detach().contiguous())
 
-        if activation == "topk":
+        if lazy:
+            pass
+        elif activation == "topk":
             values, indices = ops.topk(pre, k, tile_max=tile_max)
         else:
             values, indices = ops.groupmax(pre, k)
@@ -222,8 +305,11 @@ class FusedEncoder(torch.autograd.Function):
         ctx.k = k
         ctx.lead = lead
         ctx.in_shape = input.shape
-        ctx.mark_non_differentiable(indices, pre)
         ctx.set_materialize_grads(False)        # no (N, M) zero tensor for the ignored grad_preacts
+        if lazy:
+            ctx.mark_non_differentiable(indices)
+            return values.reshape(*lead, k), indices.reshape(*lead, k), pre
+        ctx.mark_non_differentiable(indices, pre)
         return (values.reshape(*lead, k), indices.reshape(*lead, k), pre.reshape(*lead, pre.shape[-1]))
 
     @staticmethod
@@ -231,13 +317,13 @@ class FusedEncoder(torch.autograd.Function):
         rows, weight, bias, indices, b_dec, shift = ctx.saved_tensors
         grad_input = grad_weight = grad_bias = grad_bdec = None
         if grad_values is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if ctx.empty:
             need = ctx.needs_input_grad
             return (torch.zeros(ctx.in_shape, dtype=torch.float32, device=weight.device) if need[0] else None,
                     torch.zeros_like(weight) if need[1] else None,
                     torch.zeros_like(bias) if bias is not None and need[2] else None, None, None,
-                    torch.zeros_like(b_dec) if b_dec is not None and need[5] else None)
+                    torch.zeros_like(b_dec) if b_dec is not None and need[5] else None, None)
         M = weight.shape[0]
         gv = grad_values.reshape(-1, ctx.k).contiguous()
         if weight.dtype != torch.float32:
@@ -281,9 +367,11 @@ class FusedEncoder(torch.autograd.Function):
             torch.autograd.graph.increment_version(weight)
             if shadow is not None:
                 register_bf16_shadow(weight, shadow)
-        return grad_input, grad_weight, grad_bias, None, None, grad_bdec
+        return grad_input, grad_weight, grad_bias, None, None, grad_bdec, None
 
 
-def fused_encoder(input, weight, bias, k: int, activation: Literal["groupmax", "topk"]) -> EncoderOutput:
-    """nn.Linear + ReLU + `activation`, with the sparse backward (fused_encoder.py:90-103)."""
-    return EncoderOutput(*FusedEncoder.apply(input, weight, bias, k, activation))
+def fused_encoder(input, weight, bias, k: int, activation: Literal["groupmax", "topk"],
+                  lazy_pre_acts: bool | None = None) -> EncoderOutput:
+    """nn.Linear + ReLU + `activation`, with the sparse backward (fused_encoder.py:90-103).
+    lazy_pre_acts (not in the reference): see FusedEncoder.forward."""
+    return EncoderOutput(*FusedEncoder.apply(input, weight, bias, k, activation, None, lazy_pre_acts))

@@ -200,6 +200,77 @@ def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None, tile_max: Tensor 
     return vals, idx
 
 
+LAZY_CAP = 4096          # chunks (8 latents each) a token's candidate list can hold (csrc/lazy.hip)
+LAZY_MAX_K = 256
+
+
+def lazy_split(M: int) -> int:
+    """Latents computed the ordinary way by encode_topk_lazy (the first M_a of M): about M / 4,
+    whole 256-latent tiles. Measured at the headline shape (benchmarks/lazy_bench.py): M/8 13.2 ms,
+    3M/16 13.9 (fewer 128-latent blocks than k: that top-k sweeps its rows), M/4 12.6, 3M/8 12.6."""
+    return max(256, -(-(M // 4) // 256) * 256)
+
+
+def lazy_eligible(N: int, D: int, M: int, k: int) -> bool:
+    """Shapes encode_topk_lazy takes (and pays off on): bf16, the 256x256 kernel on both parts."""
+    Ma = lazy_split(M)
+    return (k <= LAZY_MAX_K and D % 64 == 0 and M % 8 == 0 and M - Ma >= 256 and Ma >= 4 * k
+            and encoder_preacts_uses_tile256(N, D, Ma))
+
+
+def encode_topk_lazy(x: Tensor, W: Tensor, bias: Tensor | None, k: int, fallback: bool = True):
+    """top-k of relu(x @ W.T + bias) without storing the (N, M) matrix (include/sparsify_hip.h,
+    "top-k without the (N, M) matrix"; fused_encoder.py:29-33 when pre_acts is not read).
+    Returns (vals, idx, flag): the same set as topk(encoder_preacts(...)), value-descending;
+    flag is a device int32, non-zero when a candidate list overflowed -- with fallback=True the
+    ordinary path has then been run behind it on the device (no host round trip) and the outputs
+    are right either way."""
+    _req(x, "x", torch.bfloat16, 2)
+    _req(W, "weight", torch.bfloat16, 2)
+    if bias is not None:
+        _req(bias, "bias", torch.bfloat16, 1)
+    N, D = x.shape
+    M = W.shape[0]
+    if W.shape[1] != D or (bias is not None and bias.shape[0] != M):
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)}, weight {tuple(W.shape)}")
+    Ma = lazy_split(M)
+    if not (k <= LAZY_MAX_K and D % 64 == 0 and M % 8 == 0 and Ma >= k and M - Ma >= 8):
+        raise ValueError(f"encode_topk_lazy: unsupported shape D={D} M={M} k={k}")
+    lib = _lib.load()
+    st = _stream(x)
+    # 1. the first Ma latents, the ordinary way
+    pre_a, tmax_a = encoder_preacts(x, W[:Ma], None if bias is None else bias[:Ma], want_tile_max=True)
+    vals_a, idx_a = topk(pre_a, k, tile_max=tmax_a)
+    # 2. per-token threshold
+    tau = torch.empty(N, dtype=torch.bfloat16, device=x.device)
+    check(lib.sphip_row_min(vals_a.data_ptr(), N, k, tau.data_ptr(), st), "sphip_row_min")
+    # 3. the other latents: candidate chunks only
+    ws = _workspace(x.device, lib.sphip_lazy_workspace_bytes(N, LAZY_CAP), "lazy")
+    _ev = timer.start("sphip_encoder_preacts_emit", x)
+    check(lib.sphip_encoder_preacts_emit(x.data_ptr(), W.data_ptr() + Ma * D * 2, None if bias is None else bias.data_ptr() + Ma * 2,
+                                         N, D, M - Ma, Ma, tau.data_ptr(), LAZY_CAP, 1, ws.data_ptr(), ws.numel(), st),
+          "sphip_encoder_preacts_emit")
+    timer.stop(_ev, x)
+    # 4. selection
+    vals = torch.empty(N, k, dtype=torch.bfloat16, device=x.device)
+    idx = torch.empty(N, k, dtype=torch.int64, device=x.device)
+    _ev = timer.start("sphip_topk_candidates", x)
+    check(lib.sphip_topk_candidates(vals_a.data_ptr(), idx_a.data_ptr(), tau.data_ptr(), N, k, LAZY_CAP, ws.data_ptr(),
+                                    ws.numel(), vals.data_ptr(), idx.data_ptr(), st), "sphip_topk_candidates")
+    timer.stop(_ev, x)
+    flag = ws[:4].view(torch.int32)
+    if fallback:
+        # 5. predicated: both launches return at once unless the flag is up
+        full = _workspace(x.device, N * M * 2, "lazy_full").view(torch.bfloat16)[:N * M].view(N, M)
+        T = -(-M // TOPK_TILE)
+        tm = _workspace(x.device, -(-N // 64) * T * 64 * 2, "lazy_full_tmax")
+        check(lib.sphip_encoder_preacts_if(flag.data_ptr(), x.data_ptr(), W.data_ptr(), _ptr(bias), full.data_ptr(),
+                                           tm.data_ptr(), N, D, M, 1, st), "sphip_encoder_preacts_if")
+        check(lib.sphip_topk_if(flag.data_ptr(), full.data_ptr(), BF16, None, tm.data_ptr(), N, M, k, vals.data_ptr(),
+                                idx.data_ptr(), st), "sphip_topk_if")
+    return vals, idx, flag
+
+
 def groupmax(pre: Tensor, k: int):
     _req(pre, "pre_acts", ndim=2)
     N, M = pre.shape

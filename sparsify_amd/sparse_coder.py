@@ -130,6 +130,10 @@ class SkipProduct(torch.autograd.Function):
 
 
 class SparseCoder(nn.Module):
+    lazy_pre_acts: bool | None = None
+    """(not in the reference) True: forwards that do not read pre_acts do not store them
+    (fused_encoder.LazyPreActs); None: the module default fused_encoder.LAZY_PRE_ACTS."""
+
     def __init__(
         self,
         d_in: int,
@@ -226,12 +230,15 @@ class SparseCoder(nn.Module):
         return self.encoder.weight.dtype
 
     # ------------------------------------------------------------------ hot path
-    def encode(self, x: Tensor) -> EncoderOutput:
+    def encode(self, x: Tensor, lazy_pre_acts: bool | None = None) -> EncoderOutput:
         """Encode the input and select the top-k latents (sparse_coder.py:189-196).
-        The `x - b_dec` of the reference is fused into the encoder op."""
+        The `x - b_dec` of the reference is fused into the encoder op. lazy_pre_acts (not in the
+        reference): fused_encoder.FusedEncoder.forward."""
         b_dec = None if self.cfg.transcode else self.b_dec
+        if lazy_pre_acts is None:
+            lazy_pre_acts = self.lazy_pre_acts
         return EncoderOutput(*FusedEncoder.apply(
-            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.cfg.activation, b_dec))
+            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.cfg.activation, b_dec, lazy_pre_acts))
 
     def decode(self, top_acts: Tensor, top_indices: Tensor) -> Tensor:
         """sparse_coder.py:198-202; the bias add is fused into the gather kernel."""
@@ -248,7 +255,9 @@ class SparseCoder(nn.Module):
                 num_dead: int | None = None) -> ForwardOutput:
         """num_dead (not in the reference): int(dead_mask.sum()) if the caller already holds it;
         otherwise it is read here, which makes the host wait for the device mid-forward."""
-        top_acts, top_indices, pre_acts = self.encode(x)
+        # AuxK and multi-top-k read pre_acts (sparse_coder.py:240, 257): they get the stored matrix
+        reads_pre = self.cfg.multi_topk or dead_mask is not None
+        top_acts, top_indices, pre_acts = self.encode(x, lazy_pre_acts=False if reads_pre else None)
 
         if y is None:
             y = x

@@ -101,6 +101,10 @@ class Trainer:
                     else:
                         self.saes[name] = SparseCoder(widths[hook], cfg.sae, self.device, dtype=torch.float32)
 
+        if cfg.lazy_pre_acts:
+            for sae in self.saes.values():
+                sae.lazy_pre_acts = True
+
         # the source yields one micro-batch per item (the reference counts sequences:
         # len(dataset) // batch_size, trainer.py:90)
         num_batches = max(len(source), 1) if hasattr(source, "__len__") else 1
