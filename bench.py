@@ -77,14 +77,17 @@ def cpu_baseline(w: dict, tokens: int, budget_s: float = 25.0) -> dict:
                       f"the reference's (N*k,D) fp32 temporary forbids the GPU batch size on CPU"}
 
 
-def newest_profile():
-    """The newest committed counter summary (profiles/r*_pmc_summary.json, made on the GPU box by
+def newest_profile(variant: str = ""):
+    """The newest committed counter summary of this command (profiles/rNN_vNN_pmc_summary.json; with
+    `variant`, rNN_vNN_<variant>_pmc_summary.json: profiles of A/B switches are not the default run's), made on the GPU box by
     benchmarks/profile.sh from this command: kernel-trace stats + FETCH_SIZE, WRITE_SIZE, TCC hit/miss
     and SQ/GRBM passes in runs of their own, FETCH_SIZE doubled for gfx950). Counters cannot be read
     inside a timed run, so the bench line quotes the profile's numbers next to its own live timings."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")),
+    want = re.compile(r"^r\d+_v\d+_" + (variant + "_" if variant else "") + r"pmc_summary\.json$")
+    files = sorted((f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json"))
+                    if want.match(os.path.basename(f))),
                    key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])      # r01_v9 < r01_v10
     if not files:
         return None, {}
@@ -111,8 +114,8 @@ def kernel_reports(N: int, D: int, M: int, k: int):
     the kernels it launches as named in the rocprof summaries)."""
     G = 1 << 30
     return [
-        ("sphip_gather_rows_weighted", "decode: sum of k W_dec rows per token + b_dec (L2-resident gather; "
-         "includes bucketing and the slice-major copy of W_dec)", "L2", N * (k * D * 4 + D * 4),
+        ("sphip_gather_rows_weighted", "decode: sum of k W_dec rows per token + b_dec (L2-resident gather from the "
+         "slice-major copy of W_dec the decoder step leaves; includes bucketing)", "L2", N * (k * D * 4 + D * 4),
          ["sphip::gather_l2_kernel", "sphip::bucket", "sphip::slice_major"]),
         ("sphip_segmented_weight_grad", "W_dec.grad (dense, all M rows) + d top_acts: N k rows of dL/dy gathered, "
          "W_dec read, gradient written", "L2", N * k * D * 4 + 2 * (M * D * 4),
@@ -124,7 +127,7 @@ def kernel_reports(N: int, D: int, M: int, k: int):
         ("sphip_topk", "row top-k from the block maxima: the maxima + one 256-B block per selected latent",
          "HBM", N * (M // 128) * 2 + N * k * 256, ["sphip::topk_kernel"]),
         ("sphip_decoder_project_signsgd", "decoder step tail: projected gradient + sign step + re-normalisation, "
-         "W_dec and its gradient read, W_dec written", "HBM", 3 * M * D * 4, ["sphip::decoder_row_resident_kernel"]),
+         "W_dec and its gradient read, W_dec and its slice-major copy written", "HBM", 4 * M * D * 4, ["sphip::decoder_row_resident_kernel"]),
         ("sphip_vec_mat", "b_dec's encoder-side gradient gb^T W_enc: one pass over encoder.weight", "HBM", M * D * 4,
          ["sphip::col_partial_kernel<float"]),
     ]
@@ -242,7 +245,7 @@ def main():
                       if n in kern) / args.steps
         flops = 2.0 * N * D * M / (world if shard else 1)        # algorithmic FLOP per step and rank
         tflops = flops / (gemm_ms * 1e-3) / 1e12
-        prof_name, prof = newest_profile() if headline else (None, {})
+        prof_name, prof = newest_profile("lazy" if args.lazy_pre_acts else "") if headline else (None, {})
         roof = {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
                 "kernel": "encoder_gemm256_kernel (sphip_encoder_preacts)", "ms": gemm_ms,

@@ -139,8 +139,11 @@ int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, int64_t k, 
  * grad-input gather of FusedEncoder.backward, fused_encoder.py:58-64:
  *   out[n,:] = sum_s coeff[n,s] * table[idx[n,s],:]  (+ bias[:] if bias != NULL)
  * idx (N,k) int64 in [0,M); coeff (N,k) of coeff_dtype; table (M,D) fp32; out (N,D) fp32.
- * fp32 accumulation in slot order s = 0..k-1 (deterministic). A negative index marks an
- * inactive slot (latent-sharded decode: the latent lives on another GPU); it is skipped. */
+ * fp32 accumulation in slot order s = 0..k-1 (deterministic). An index outside [0,M) --
+ * negative, or >= M -- marks an inactive slot (latent-sharded decode: the latent lives on
+ * another GPU) and is skipped, here and in the segment / gradient entry points below;
+ * torch.embedding_bag (utils.py:88) raises on such an index instead: a binding that wants that
+ * checks the range before the call. */
 int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff, int coeff_dtype,
                                const float* table, const float* bias, float* out, int64_t N,
                                int64_t k, int64_t M, int64_t D, void* stream);
