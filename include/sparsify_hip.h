@@ -279,12 +279,13 @@ int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D
  * not part of the reference tree (parity unpinned; the host class schedule_free.py states the
  * algorithm it restates). The decoder form first projects g on the orthogonal complement of
  * the row (sparse_coder.py:281-295) and, with renorm != 0, normalises the new row
- * (sparse_coder.py:273-279); D <= 4096. */
+ * (sparse_coder.py:273-279); D <= 4096. slice_major: NULL, or the [D/32][M][32] copy of W
+ * (sphip_slice_major_f32) to rewrite with the finished rows in the same pass (D % 32 == 0). */
 int sphip_schedulefree_signsgd_step(float* p, float* z, const float* g, int64_t n, float lr,
                                     float beta, float c, void* bf16_shadow, void* stream);
 int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M,
                                             int64_t D, float lr, float beta, float c, int renorm,
-                                            void* stream);
+                                            float* slice_major, void* stream);
 
 /* The encoder weight gradient fused with its SignSGD step (fused_encoder.py:67-77 +
  * sign_sgd.py:23): the segmented reduction of sphip_segmented_weight_grad (without dcoeff), but

@@ -407,10 +407,12 @@ __global__ __launch_bounds__(256) void sf_signsgd_kernel(float* __restrict__ p, 
 // Decoder rows: the gradient is first projected on the row's orthogonal complement
 // (sparse_coder.py:281-295, W = y), and with renorm the new y is normalised in the same pass
 // (the set_decoder_norm_to_unit_norm that opens the next step). Row-resident, D <= 1024 R.
-template <int R>
+// SM: the finished row also goes to the slice-major copy, as in decoder_row_resident_kernel.
+template <int R, bool SM = false>
 __global__ __launch_bounds__(256) void sf_decoder_kernel(float* __restrict__ W, float* __restrict__ Z,
                                                          const float* __restrict__ G, int D, float lr, float w_undo,
-                                                         float c, float w_y, int renorm, float eps) {
+                                                         float c, float w_y, int renorm, float eps,
+                                                         float* __restrict__ sm = nullptr, int64_t M = 0) {
     __shared__ float red[16];
     float* w = W + (int64_t)blockIdx.x * D;
     float* zr = Z + (int64_t)blockIdx.x * D;
@@ -459,6 +461,8 @@ __global__ __launch_bounds__(256) void sf_decoder_kernel(float* __restrict__ W, 
         if (col < D) {
             *reinterpret_cast<float4*>(w + col) = y[i];
             *reinterpret_cast<float4*>(zr + col) = z[i];
+            const int c4 = col >> 2;
+            if (SM) *reinterpret_cast<float4*>(sm + (((int64_t)(c4 >> 3) * M + blockIdx.x) * 8 + (c4 & 7)) * 4) = y[i];
         }
     }
 }
@@ -751,16 +755,26 @@ extern "C" int sphip_schedulefree_signsgd_step(float* p, float* z, const float* 
 }
 
 extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr,
-                                                       float beta, float c, int renorm, void* stream) {
+                                                       float beta, float c, int renorm, float* slice_major, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W && Z && G, SPHIP_EINVAL, "decoder_schedulefree_signsgd_step: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
                   "decoder_schedulefree_signsgd_step: bad shape / beta");
     SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 && ((uintptr_t)G & 15) == 0,
                   SPHIP_EUNSUPPORTED, "decoder_schedulefree_signsgd_step: needs D %% 4 == 0, D <= 4096, 16-byte aligned rows");
+    SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0), SPHIP_EINVAL,
+                  "decoder_schedulefree_signsgd_step: the slice-major copy needs D %% 32 == 0 and a 16-byte aligned buffer");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)M), block(256);
     const float wu = 1.f - 1.f / beta, wy = 1.f - beta;
+    if (slice_major != nullptr) {
+        float* sm = slice_major;
+        if (D <= 1024) hipLaunchKernelGGL((sf_decoder_kernel<1, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
+        else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
+        else hipLaunchKernelGGL((sf_decoder_kernel<4, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
+        SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
+        return SPHIP_OK;
+    }
     if (D <= 1024) hipLaunchKernelGGL((sf_decoder_kernel<1>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     else hipLaunchKernelGGL((sf_decoder_kernel<4>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);

@@ -16,12 +16,15 @@
 
 namespace sphip {
 
+// an index outside [0, M) marks an inactive slot (sparsify_hip.h)
+__device__ __forceinline__ bool off(int64_t j, int64_t M) { return (unsigned long long)j >= (unsigned long long)M; }
+
 template <typename CT, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ idx,
                                                           const CT* __restrict__ coeff,
                                                           const float* __restrict__ table,
                                                           const float* __restrict__ bias,
-                                                          float* __restrict__ out, int k, int D) {
+                                                          float* __restrict__ out, int k, int D, int64_t M) {
     const int64_t n = blockIdx.y;
     const int col = (blockIdx.x * 256 + threadIdx.x) * VEC;
     if (col >= D) return;
@@ -44,8 +47,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
             // 0 and row 0 as a stand-in address (always cache-resident), so the unrolled load
             // batch stays branch-free
             const int64_t j = ip[s + u];
-            rp[u] = tcol + (j < 0 ? 0 : j) * (int64_t)D;
-            w[u] = j < 0 ? 0.f : Elem<CT>::load(cp, s + u);
+            rp[u] = tcol + (off(j, M) ? 0 : j) * (int64_t)D;
+            w[u] = off(j, M) ? 0.f : Elem<CT>::load(cp, s + u);
         }
         if (VEC == 4) {
             float4 r[U];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
         }
     }
     for (; s < k; ++s) {
-        if (ip[s] < 0) continue;
+        if (off(ip[s], M)) continue;
         const float* rp = tcol + ip[s] * (int64_t)D;
         const float w = Elem<CT>::load(cp, s);
 #pragma unroll
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void gather_rows_sliced_kernel(const int64_t* 
                                                                  const CT* __restrict__ coeff,
                                                                  const float* __restrict__ table,
                                                                  const float* __restrict__ bias,
-                                                                 float* __restrict__ out, int N, int k, int D) {
+                                                                 float* __restrict__ out, int N, int k, int D, int64_t M) {
     // one wave per token, so the index / weight loads stay scalar (half a wave per token with
     // 128-column slices measured 5 % slower)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256) void gather_rows_sliced_kernel(const int64_t* 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = ip[s + u];
-            rp[u] = tcol + (j < 0 ? 0 : j) * (int64_t)D;
-            w[u] = j < 0 ? 0.f : Elem<CT>::load(cp, s + u);
+            rp[u] = tcol + (off(j, M) ? 0 : j) * (int64_t)D;
+            w[u] = off(j, M) ? 0.f : Elem<CT>::load(cp, s + u);
         }
         float4 r[U];
 #pragma unroll
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void gather_rows_sliced_kernel(const int64_t* 
     }
     for (; s < k; ++s) {
         const int64_t j = ip[s];
-        if (j < 0) continue;
+        if (off(j, M)) continue;
         const float4 r = *reinterpret_cast<const float4*>(tcol + j * (int64_t)D);
         const float w = Elem<CT>::load(cp, s);
         acc.x = fmaf(w, r.x, acc.x);
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(256) void gather_rows_sliced_kernel(const int64_t* 
     __builtin_nontemporal_store(t, reinterpret_cast<f4*>(out + n * (int64_t)D + col));
 }
 
-// Validates idx on the device is not done (cost); the host wrapper guarantees the range
-// because idx always comes from sphip_topk / sphip_groupmax on the same M.
+// Indices outside [0, M) are inactive slots and read nothing (sparsify_hip.h).
+
 
 }  // namespace sphip
 
@@ -171,9 +174,9 @@ extern "C" int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff,
     if (sliced) {
         dim3 grid((unsigned)cdiv(N, 4), (unsigned)(D / 256)), block(256);
         if (coeff_dtype == SPHIP_F32)
-            hipLaunchKernelGGL((gather_rows_sliced_kernel<float>), grid, block, 0, s, idx, (const float*)coeff, table, bias, out, (int)N, (int)k, (int)D);
+            hipLaunchKernelGGL((gather_rows_sliced_kernel<float>), grid, block, 0, s, idx, (const float*)coeff, table, bias, out, (int)N, (int)k, (int)D, M);
         else
-            hipLaunchKernelGGL((gather_rows_sliced_kernel<bf16_t>), grid, block, 0, s, idx, (const bf16_t*)coeff, table, bias, out, (int)N, (int)k, (int)D);
+            hipLaunchKernelGGL((gather_rows_sliced_kernel<bf16_t>), grid, block, 0, s, idx, (const bf16_t*)coeff, table, bias, out, (int)N, (int)k, (int)D, M);
         SPHIP_CHECK_LAUNCH("gather_rows_weighted(sliced)");
         return SPHIP_OK;
     }
@@ -186,15 +189,15 @@ extern "C" int sphip_gather_rows_weighted(const int64_t* idx, const void* coeff,
         if (vec) {
             dim3 grid((unsigned)cdiv(D, 1024), (unsigned)nn), block(256);
             if (coeff_dtype == SPHIP_F32)
-                hipLaunchKernelGGL((gather_rows_kernel<float, 4>), grid, block, 0, s, ip, (const float*)coeff + n0 * k, table, bias, op, (int)k, (int)D);
+                hipLaunchKernelGGL((gather_rows_kernel<float, 4>), grid, block, 0, s, ip, (const float*)coeff + n0 * k, table, bias, op, (int)k, (int)D, M);
             else
-                hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 4>), grid, block, 0, s, ip, (const bf16_t*)coeff + n0 * k, table, bias, op, (int)k, (int)D);
+                hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 4>), grid, block, 0, s, ip, (const bf16_t*)coeff + n0 * k, table, bias, op, (int)k, (int)D, M);
         } else {
             dim3 grid((unsigned)cdiv(D, 256), (unsigned)nn), block(256);
             if (coeff_dtype == SPHIP_F32)
-                hipLaunchKernelGGL((gather_rows_kernel<float, 1>), grid, block, 0, s, ip, (const float*)coeff + n0 * k, table, bias, op, (int)k, (int)D);
+                hipLaunchKernelGGL((gather_rows_kernel<float, 1>), grid, block, 0, s, ip, (const float*)coeff + n0 * k, table, bias, op, (int)k, (int)D, M);
             else
-                hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 1>), grid, block, 0, s, ip, (const bf16_t*)coeff + n0 * k, table, bias, op, (int)k, (int)D);
+                hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 1>), grid, block, 0, s, ip, (const bf16_t*)coeff + n0 * k, table, bias, op, (int)k, (int)D, M);
         }
         SPHIP_CHECK_LAUNCH("gather_rows_weighted");
     }

@@ -637,16 +637,24 @@ def schedulefree_signsgd_step_(p: Tensor, z: Tensor, g: Tensor, lr: float, beta:
 
 
 def decoder_schedulefree_signsgd_step_(W: Tensor, Z: Tensor, G: Tensor, lr: float, beta: float, c: float,
-                                        renorm: bool = False) -> Tensor:
-    """The same for decoder rows: projected gradient, step, optional re-normalisation of y."""
+                                        renorm: bool = False, slice_major: Tensor | None = None) -> Tensor:
+    """The same for decoder rows: projected gradient, step, optional re-normalisation of y.
+    slice_major: the [D/32][M][32] buffer to rewrite with the finished rows in the same pass."""
     _req(W, "W_dec", torch.float32, 2)
     _req(Z, "z", torch.float32, 2)
     _req(G, "W_dec.grad", torch.float32, 2)
     if Z.shape != W.shape or G.shape != W.shape:
         raise ValueError("decoder_schedulefree_signsgd_step: shape mismatch")
+    if slice_major is not None:
+        _req(slice_major, "slice_major", torch.float32)
+        if slice_major.numel() != W.numel() or W.shape[1] % 32:
+            raise ValueError("decoder_schedulefree_signsgd_step: slice_major must hold M * D floats, D % 32 == 0")
+    _ev = timer.start("sphip_decoder_schedulefree_signsgd_step", W)
     check(_lib.load().sphip_decoder_schedulefree_signsgd_step(W.data_ptr(), Z.data_ptr(), G.data_ptr(), W.shape[0],
                                                              W.shape[1], float(lr), float(beta), float(c), int(renorm),
-                                                             _stream(W)), "sphip_decoder_schedulefree_signsgd_step")
+                                                             _ptr(slice_major), _stream(W)),
+          "sphip_decoder_schedulefree_signsgd_step")
+    timer.stop(_ev, W)
     return W
 
 

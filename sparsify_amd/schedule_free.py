@@ -164,8 +164,12 @@ class ScheduleFreeWrapper:
                     else:
                         self._exchange_step(*item, overlap=False)
                     continue
+                sm = None
                 if project:
-                    ops.decoder_schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, renorm)
+                    # (the slice-major copy of y the L2-resident decode reads is rewritten in the same pass)
+                    sm = ops.peek_slice_major(p) if p.shape[1] % 32 == 0 else None
+                    ops.decoder_schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, renorm,
+                                                           slice_major=sm)
                     if renorm:
                         self.base.renormalised.add(id(p))
                 else:
@@ -174,6 +178,8 @@ class ScheduleFreeWrapper:
                     if shadow is not None:
                         register_bf16_shadow(p, shadow)
                 torch.autograd.graph.increment_version(p)
+                if sm is not None:
+                    ops.register_slice_major(p, sm)
             group["k"] += 1
         for item in sorted(deferred, key=lambda it: it[5]):       # encoder matrices first (sign_sgd.py)
             self._exchange_step(*item, overlap=True)

@@ -743,3 +743,24 @@ def test_decoder_step_writes_the_slice_major_copy(device, D, renorm):
     torch.cuda.synchronize()
     assert torch.equal(buf, want)
     assert torch.equal(buf, got.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
+
+
+@pytest.mark.parametrize("D", [64, 1024, 2560, 4096])
+@pytest.mark.parametrize("renorm", [False, True])
+def test_schedulefree_decoder_step_writes_the_slice_major_copy(device, D, renorm):
+    """sphip_decoder_schedulefree_signsgd_step with a slice-major buffer: y and z bit for bit what
+    the call without the buffer leaves, the buffer the slice-major form of the new y."""
+    from sparsify_amd import ops
+    M = 777
+    g = torch.Generator(device="cuda").manual_seed(D + 1)
+    W0 = torch.randn(M, D, device="cuda", generator=g)
+    W0 /= W0.norm(dim=1, keepdim=True)
+    Z0 = W0 + 0.01 * torch.randn(M, D, device="cuda", generator=g)
+    G = torch.randn(M, D, device="cuda", generator=g)
+    Wp, Zp = W0.clone(), Z0.clone()
+    ops.decoder_schedulefree_signsgd_step_(Wp, Zp, G, 3e-3, 0.95, 0.25, renorm)
+    Wg, Zg = W0.clone(), Z0.clone()
+    buf = torch.full((D // 32, M, 32), float("nan"), device="cuda")
+    ops.decoder_schedulefree_signsgd_step_(Wg, Zg, G, 3e-3, 0.95, 0.25, renorm, slice_major=buf)
+    assert torch.equal(Wg, Wp) and torch.equal(Zg, Zp)
+    assert torch.equal(buf, Wg.view(M, D // 32, 32).permute(1, 0, 2).contiguous())

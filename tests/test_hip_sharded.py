@@ -265,14 +265,17 @@ def test_synthetic_transcoder_run_follows_the_oracle_into_its_collapse(device):
         assert abs(got_active - want_active) <= 0.3 * want_active, rows[step]
 
 
-def test_inactive_slots_are_skipped(device):
-    """idx = -1 marks a slot owned by another shard: no contribution anywhere."""
+@pytest.mark.parametrize("mark", [-1, "past_M"])
+def test_inactive_slots_are_skipped(device, mark):
+    """idx = -1 (or any index outside [0, M), sparsify_hip.h) marks a slot owned by another shard:
+    no contribution anywhere, no read outside the table."""
     from sparsify_amd import ops
     torch.manual_seed(0)
     N, k, M, D = 40, 8, 64, 128
     idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
     drop = torch.rand(N, k) < 0.5
-    idx_m = torch.where(drop, torch.full_like(idx, -1), idx).cuda()
+    off = torch.full_like(idx, -1) if mark == -1 else M + torch.randint(0, 1 << 40, idx.shape)
+    idx_m = torch.where(drop, off, idx).cuda()
     coeff = torch.randn(N, k)
     table = torch.randn(M, D)
     g = torch.randn(N, D)
