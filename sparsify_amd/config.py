@@ -78,7 +78,7 @@ class TrainConfig(_Serializable):
     """(not in the reference; BASELINE.json configs[4]) split every coder's latents over the ranks
     (sharded.ShardedSparseCoder): all ranks see the same tokens, the only exchanges are the top-k
     candidates and the partial reconstructions, gradients and optimizer state stay shard-local.
-    Plain top-k FVU step only (no AuxK, multi-top-k or end-to-end loss)."""
+    The top-k FVU step with AuxK, multi-top-k and the skip connection; no end-to-end loss, no groupmax."""
     fuse_encoder_update: bool = True
     """(not in the reference) "signsgd" on one rank without gradient accumulation: apply the step of
     `encoder.weight` inside its gradient kernel (same update; the (M, D) gradient is never
@@ -107,9 +107,8 @@ class TrainConfig(_Serializable):
                 "Distributing modules across ranks is not compatible with the "
                 "cross-entropy or KL divergence losses."
             )
-        if self.shard_latents and (self.distribute_modules or self.loss_fn != "fvu" or self.auxk_alpha > 0
-                                   or self.sae.multi_topk or self.sae.activation != "topk"):
-            raise ValueError("`shard_latents` implements the plain top-k FVU step: no distribute_modules, "
-                             "ce / kl loss, AuxK, multi-top-k or groupmax")
+        if self.shard_latents and (self.distribute_modules or self.loss_fn != "fvu" or self.sae.activation != "topk"):
+            raise ValueError("`shard_latents` implements the top-k FVU step (with AuxK, multi-top-k and the skip "
+                             "connection): no distribute_modules, ce / kl loss or groupmax")
         if not self.init_seeds:
             raise ValueError("Must specify at least one random seed.")

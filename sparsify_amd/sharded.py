@@ -15,6 +15,15 @@ Backward needs no collective at all: dL/d sae_out is replicated, every rank redu
 gradient rows of its own latents, and the gradient of a selected activation is needed only
 by its owner. The replicated b_dec is the one shared parameter; its gradient (D floats) is
 summed over ranks once per step by reduce_shared_grads().
+
+The other terms of SparseCoder.forward take the same route (sharded_select below): AuxK
+(sparse_coder.py:230-251) is a second selection, k_aux of the dead latents -- every shard offers
+its k_aux best dead latents (its slice of the replicated dead mask), the merge keeps the k_aux
+best of all, the partial reconstructions of the residual are summed; multi-top-k
+(sparse_coder.py:256-262) is the same with 4k and no mask. Neither sends a gradient into the
+encoder (the reference drops grad_preacts, fused_encoder.py:53,87). The skip connection
+(sparse_coder.py:219-222) is replicated: every rank holds W_skip and computes x W_skip^T and its
+gradient in full, so the replicas stay identical without a collective.
 """
 from __future__ import annotations
 
@@ -25,7 +34,7 @@ from torch import Tensor, nn
 from . import ops, parallel
 from .config import SparseCoderConfig
 from .fused_encoder import _autocast_bf16, bf16_shadow
-from .sparse_coder import ForwardOutput, ResidualLoss
+from .sparse_coder import ForwardOutput, ResidualLoss, SkipProduct, _AddSkip
 from .utils import SparseDecode
 
 
@@ -44,12 +53,23 @@ def merge_candidates(cand_v: Tensor, cand_i: Tensor, k: int, lo: int, hi: int):
     return mv, gidx, local_idx
 
 
+def sharded_select(pre: Tensor, k_sel: int, lo: int, hi: int, keep_local: Tensor | None = None):
+    """Global top-k_sel over the shards' pre-activations, optionally among the latents a mask keeps:
+    local top-k (at most k_sel candidates per shard), candidate all-gather, merge. A shard with
+    fewer kept latents than it offers fills up with masked-out entries (value -inf), which no merge
+    prefers to a kept latent of another shard."""
+    kk = min(k_sel, pre.shape[1])
+    lv, li = ops.topk(pre, kk, keep_mask=keep_local)
+    cand_v, cand_i = parallel.gather_topk_candidates(lv, li, lo)
+    return merge_candidates(cand_v, cand_i, k_sel, lo, hi)
+
+
 class _ShardedEncode(torch.autograd.Function):
     """Local encoder GEMM + local top-k + candidate exchange + merge. Returns the merged
     (values, global indices) and this rank's local view of the selection."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, k: int, lo: int, hi: int, b_dec):
+    def forward(ctx, x, weight, bias, k: int, lo: int, hi: int, b_dec, want_pre: bool = False):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         low = _autocast_bf16()
         if b_dec is not None:
@@ -69,15 +89,20 @@ class _ShardedEncode(torch.autograd.Function):
         ops.forget_segments(local_idx)
         ctx.save_for_backward(rows, weight, local_idx, b_dec)
         ctx.k = k
-        ctx.mark_non_differentiable(gidx, local_idx)
         ctx.set_materialize_grads(False)
-        return mv, gidx, local_idx
+        if want_pre:
+            # the shard's pre-activations, for the AuxK / multi-top-k selections (no gradient:
+            # fused_encoder.py:53,87)
+            ctx.mark_non_differentiable(gidx, local_idx, pre)
+            return mv, gidx, local_idx, pre
+        ctx.mark_non_differentiable(gidx, local_idx)
+        return mv, gidx, local_idx, None
 
     @staticmethod
-    def backward(ctx, grad_values, _g1, _g2):
+    def backward(ctx, grad_values, _g1, _g2, _g3):
         rows, weight, local_idx, b_dec = ctx.saved_tensors
         if grad_values is None:
-            return (None,) * 7
+            return (None,) * 8
         gv = grad_values.reshape(-1, ctx.k).contiguous()
         seg = ops.cached_segments(local_idx, weight.shape[0])
         gW, gb, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True)
@@ -85,7 +110,7 @@ class _ShardedEncode(torch.autograd.Function):
         if b_dec is not None and ctx.needs_input_grad[6]:
             # this shard's part of -sum_n grad_x[n,:]; summed over shards by reduce_shared_grads()
             g_bdec = ops.vec_mat(gb, weight.detach(), -1.0)
-        return None, gW, gb, None, None, None, g_bdec
+        return None, gW, gb, None, None, None, g_bdec, None
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -135,6 +160,9 @@ class ShardedSparseCoder(nn.Module):
                 w /= torch.norm(w, dim=1, keepdim=True) + torch.finfo(w.dtype).eps
             self.W_dec = nn.Parameter(w)
         self.b_dec = nn.Parameter(torch.zeros(d_in, dtype=dtype, device=device))
+        # replicated on every rank (sparse_coder.py:76-80)
+        self.W_skip = (nn.Parameter(torch.zeros(d_in, d_in, device=device, dtype=dtype))
+                       if cfg.skip_connection else None)
         del full
 
     @property
@@ -159,6 +187,8 @@ class ShardedSparseCoder(nn.Module):
             "encoder.bias": parallel.all_gather_rows(self.encoder.bias.data),
             "encoder.weight": parallel.all_gather_rows(self.encoder.weight.data),
         }
+        if self.W_skip is not None:
+            tensors["W_skip"] = self.W_skip.data
         if parallel.rank() == 0:
             path = Path(path)
             path.mkdir(parents=True, exist_ok=True)
@@ -166,25 +196,60 @@ class ShardedSparseCoder(nn.Module):
             with open(path / "cfg.json", "w") as f:
                 json.dump({**self.cfg.to_dict(), "d_in": self.d_in}, f)
 
+    def _decode_all(self, local_idx: Tensor, acts: Tensor) -> Tensor:
+        """Full reconstruction from a merged selection: this rank's partial sum over the slots it
+        owns, summed over ranks, plus b_dec. The decode-side gradient of the replicated b_dec is
+        identical on every rank: 1/W of it is kept here so that reduce_shared_grads() (one SUM
+        over ranks, which also adds up the shard-local encoder-side terms) yields the unsharded
+        gradient."""
+        partial = SparseDecode.apply(local_idx, self.W_dec, acts.to(self.dtype), None)
+        return _AllReduceSum.apply(partial) + _ScaleGrad.apply(self.b_dec, 1.0 / parallel.world_size())
+
     @torch.autocast("cuda", dtype=torch.bfloat16, enabled=torch.cuda.is_available())
-    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None) -> ForwardOutput:
-        if dead_mask is not None or self.cfg.multi_topk or self.cfg.activation != "topk":
-            raise NotImplementedError("the latent-sharded coder implements the plain top-k FVU step")
+    def forward(self, x: Tensor, y: Tensor | None = None, *, dead_mask: Tensor | None = None,
+                num_dead: int | None = None) -> ForwardOutput:
+        """dead_mask: the (num_latents,) mask of the whole dictionary, identical on every rank (the
+        Trainer's counters see the merged selection); num_dead as in SparseCoder.forward."""
+        if self.cfg.activation != "topk":
+            raise NotImplementedError("the latent-sharded coder selects with top-k (groupmax groups would straddle shards)")
         b_dec = None if self.cfg.transcode else self.b_dec
-        top_acts, top_indices, local_idx = _ShardedEncode.apply(
-            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.lo, self.hi, b_dec)
+        want_pre = dead_mask is not None or self.cfg.multi_topk
+        top_acts, top_indices, local_idx, pre = _ShardedEncode.apply(
+            x, self.encoder.weight, self.encoder.bias, self.cfg.k, self.lo, self.hi, b_dec, want_pre)
         if y is None:
             y = x
-        partial = SparseDecode.apply(local_idx, self.W_dec, top_acts.to(self.dtype), None)
-        # the decode-side gradient of the replicated b_dec is identical on every rank: keep 1/W
-        # of it here so that reduce_shared_grads() (one SUM over ranks, which also adds up the
-        # shard-local encoder-side terms) yields the unsharded gradient
-        sae_out = _AllReduceSum.apply(partial) + _ScaleGrad.apply(self.b_dec, 1.0 / parallel.world_size())
+        sae_out = self._decode_all(local_idx, top_acts)
+        if self.W_skip is not None:
+            sae_out = _AddSkip.apply(sae_out, SkipProduct.apply(x.reshape(-1, x.shape[-1]), self.W_skip, _autocast_bf16()))
         y2 = y.reshape(-1, y.shape[-1]).contiguous()
         tv = ops.total_variance(y2)
-        fvu, _ = ResidualLoss.apply(sae_out, y, tv)
+        fvu, e = ResidualLoss.apply(sae_out, y2, tv)
         zero = sae_out.new_zeros(())               # a fill kernel: new_tensor(0.0) is a blocking host copy
-        return ForwardOutput(sae_out, top_acts, top_indices, fvu, zero, zero)
+
+        auxk_loss = zero
+        if dead_mask is not None and num_dead is None:
+            num_dead = int(dead_mask.sum())
+        if dead_mask is not None and num_dead > 0:                                  # sparse_coder.py:230-251
+            if dead_mask.shape[0] != self.num_latents:
+                raise ValueError(f"dead_mask must cover the whole dictionary ({self.num_latents} latents)")
+            k_aux = y.shape[-1] // 2
+            scale = min(num_dead / k_aux, 1.0)
+            k_aux = min(k_aux, num_dead)
+            keep = dead_mask[self.lo:self.hi].contiguous()
+            aux_acts, _, aux_local = sharded_select(pre, k_aux, self.lo, self.hi, keep)
+            e_hat = self._decode_all(aux_local, aux_acts)
+            auxk_sq, _ = ResidualLoss.apply(e_hat, e, tv)
+            auxk_loss = scale * auxk_sq
+
+        multi_topk_fvu = zero
+        if self.cfg.multi_topk:                                                       # sparse_coder.py:256-262
+            top_acts, top_indices, local4 = sharded_select(pre, 4 * self.cfg.k, self.lo, self.hi)
+            sae_out = self._decode_all(local4, top_acts)
+            multi_topk_fvu, _ = ResidualLoss.apply(sae_out, y2, tv)
+
+        lead = x.shape[:-1]
+        return ForwardOutput(sae_out.reshape(*lead, -1), top_acts.reshape(*lead, -1), top_indices.reshape(*lead, -1),
+                             fvu, auxk_loss, multi_topk_fvu)
 
     @torch.no_grad()
     def reduce_shared_grads(self):

@@ -313,7 +313,7 @@ class Trainer:
             num_dead = int(n_dead)
 
         self._install_grad_hooks()
-        out = (raw(x=inputs, y=outputs, dead_mask=dead_mask, num_dead=num_dead) if num_dead is not None and isinstance(raw, SparseCoder)
+        out = (raw(x=inputs, y=outputs, dead_mask=dead_mask, num_dead=num_dead) if num_dead is not None
                else raw(x=inputs, y=outputs, dead_mask=dead_mask))
 
         ops.mark_fired_(self.did_fire[name], out.latent_indices.reshape(-1))      # trainer.py:422

@@ -16,15 +16,14 @@ def test_reference_validation_rules():
     assert isinstance(cfg.sae, SparseCoderConfig) and cfg.sae.k == 16 and cfg.sae.transcode
 
 
-@pytest.mark.parametrize("kw", [dict(distribute_modules=True), dict(loss_fn="kl"), dict(auxk_alpha=1 / 32),
-                                dict(sae=SparseCoderConfig(multi_topk=True)),
+@pytest.mark.parametrize("kw", [dict(distribute_modules=True), dict(loss_fn="kl"),
                                 dict(sae=SparseCoderConfig(activation="groupmax"))])
-def test_latent_sharding_is_the_plain_topk_step_only(kw):
+def test_latent_sharding_is_the_topk_fvu_step_only(kw):
     kw.setdefault("sae", SparseCoderConfig())
     with pytest.raises(ValueError):
         TrainConfig(shard_latents=True, **kw)
-    kw_ok = {k: v for k, v in kw.items() if k == "sae" and not (v.multi_topk or v.activation != "topk")}
-    TrainConfig(shard_latents=True, **({"sae": SparseCoderConfig()} | kw_ok))
+    TrainConfig(shard_latents=True, sae=SparseCoderConfig())
+    TrainConfig(shard_latents=True, auxk_alpha=1 / 32, sae=SparseCoderConfig(multi_topk=True, skip_connection=True))
 
 
 def test_defaults_of_the_added_switches():

@@ -150,29 +150,33 @@ def test_overlapped_exchange_over_rccl_one_rank(device):
         assert out[(opt, "exchange")]["early"] == 0
 
 
-def _shard_worker(rank, world, port, ret, save_dir):
+def _shard_worker(rank, world, port, ret, save_dir, variants=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ret[rank] = _train_small(shard=True, save_dir=save_dir)
+        ret[rank] = _train_small(shard=True, save_dir=save_dir, variants=variants)
     finally:
         dist.destroy_process_group()
 
 
-def _train_small(shard, save_dir=""):
+def _train_small(shard, save_dir="", variants=False):
+    """variants: AuxK (a latent that did not fire in the last step counts as dead: from the second step on) and multi-top-k."""
     from sparsify_amd import SparseCoderConfig, TrainConfig
     from sparsify_amd.trainer import SyntheticActivations, Trainer
-    D, M, k, N, steps = 128, 2048, 16, 512, 5
-    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h0"], save_dir=save_dir,
-                      run_name="run", save_every=10**9, wandb_log_frequency=1, shard_latents=shard)
+    D, M, k, N, steps = 128, 2048, 16, 512, 8 if variants else 5
+    extra = dict(auxk_alpha=1 / 32, dead_feature_threshold=100) if variants else {}
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, multi_topk=variants), optimizer="signsgd", hookpoints=["h0"],
+                      save_dir=save_dir, run_name="run", save_every=10**9, wandb_log_frequency=1, shard_latents=shard, **extra)
     src = SyntheticActivations(["h0"], D, N, steps, device="cuda", rank=0)      # every rank sees the same tokens
     torch.manual_seed(0)
     tr = Trainer(cfg, src, device="cuda")
-    fvus = []
+    fvus, aux = [], []
     for s in range(steps):
         tr.train_micro_batch(src.batch(s))
         fvus.append(tr.last_logged["fvu/h0"])
+        if variants:
+            aux.append((tr.last_logged["auxk/h0"], tr.last_logged["multi_topk_fvu/h0"]))
     if save_dir:
         tr.save()
         # save_best is a collective for latent shards too (every rank joins the gathers); it
@@ -180,20 +184,21 @@ def _train_small(shard, save_dir=""):
         tr.save_best({"h0": 0.0})
     torch.cuda.synchronize()
     sae = tr.saes["h0"]
-    return {"fvu": fvus, "rows": tuple(sae.encoder.weight.shape), "W_dec": sae.W_dec.detach().cpu(),
+    return {"fvu": fvus, "aux": aux, "rows": tuple(sae.encoder.weight.shape), "W_dec": sae.W_dec.detach().cpu(),
             "W_enc": sae.encoder.weight.detach().cpu(), "b_dec": sae.b_dec.detach().cpu()}
 
 
-def test_latent_sharded_trainer_matches_unsharded(device, tmp_path):
+@pytest.mark.parametrize("variants", [False, True])
+def test_latent_sharded_trainer_matches_unsharded(device, tmp_path, variants):
     """TrainConfig.shard_latents with two ranks on one GPU: each rank trains half of the latents of
     one dictionary on the same tokens. The FVU curve and the parameters follow the unsharded
     Trainer (the reconstruction is a sum of two partial sums, so a gradient at the rounding level
     may take the other sign), and the checkpoint rank 0 writes from the gathered shards is an
-    ordinary unsharded one."""
+    ordinary unsharded one. variants: with the AuxK and multi-top-k terms (their losses follow too)."""
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, ret, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, ret, str(tmp_path), variants)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -203,12 +208,18 @@ def test_latent_sharded_trainer_matches_unsharded(device, tmp_path):
             p.kill()
             pytest.fail("a rank did not finish (collective mismatch?)")
         assert p.exitcode == 0
-    ref = _train_small(shard=False)
+    ref = _train_small(shard=False, variants=variants)
     r0, r1 = ret[0], ret[1]
     assert r0["rows"] == (1024, 128) and r1["rows"] == (1024, 128)
     assert r0["fvu"] == r1["fvu"]                                   # replicated loss, identical on the ranks
     for a, b in zip(r0["fvu"], ref["fvu"]):
         assert abs(a - b) <= 2e-3 * b, (r0["fvu"], ref["fvu"])
+    if variants:
+        assert r0["aux"] == r1["aux"]
+        assert ref["aux"][-1][0] > 0 and ref["aux"][0][0] == 0      # AuxK switches on when latents have died
+        for (a_aux, a_multi), (b_aux, b_multi) in zip(r0["aux"], ref["aux"]):
+            assert abs(a_aux - b_aux) <= 5e-3 * max(b_aux, 1e-6), (r0["aux"], ref["aux"])
+            assert abs(a_multi - b_multi) <= 2e-3 * b_multi, (r0["aux"], ref["aux"])
     assert ref["fvu"][-1] < 1.0
     assert torch.equal(r0["b_dec"], r1["b_dec"])                    # the one shared parameter stays replicated
     for name in ("W_dec", "W_enc"):

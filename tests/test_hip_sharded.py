@@ -12,6 +12,15 @@ from oracle import sae_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def own_stream(torch):
+    """A stream of its own for a thread-rank: the package's scratch buffers are per (device, stream),
+    as they must be for real ranks (one process each); two thread-ranks on one stream would share them
+    and interleave their multi-kernel reductions."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.default_stream())
+    torch.cuda.set_stream(s)
+
+
 class FakeWorld:
     """Thread-per-rank collectives with the signatures of sparsify_amd.parallel."""
 
@@ -87,6 +96,7 @@ def test_sharded_equals_unsharded(device, monkeypatch, transcode):
         try:
             fw.local.rank = r
             torch.cuda.set_device(0)
+            own_stream(torch)
             lo, hi = fw.shard_range(M)
             sh = ShardedSparseCoder(D, cfg, device="cuda")
             with torch.no_grad():
@@ -128,6 +138,7 @@ def _run_sharded(fw, W, cfg, D, M, P, x, y, autocast):
         try:
             fw.local.rank = r
             torch.cuda.set_device(0)
+            own_stream(torch)
             lo, hi = fw.shard_range(M)
             sh = ShardedSparseCoder(D, cfg, device="cuda")
             with torch.no_grad():
@@ -290,3 +301,97 @@ def test_inactive_slots_are_skipped(device, mark):
     torch.testing.assert_close(gW.cpu(), ref_gW, rtol=1e-4, atol=1e-5)
     ref_dc = torch.einsum("nd,nsd->ns", g, table[idx]) * ~drop
     torch.testing.assert_close(dc.cpu(), ref_dc, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("variant", ["auxk", "auxk_few_dead", "multi_topk", "skip", "all"])
+def test_sharded_auxk_multitopk_skip_vs_oracle(device, monkeypatch, variant, W):
+    """The other terms of SparseCoder.forward on the latent-sharded coder (sparse_coder.py:219-222,
+    230-251, 256-262; no reference code for the sharding itself), fp32, against the CPU oracle of
+    the unsharded reference coder: identical selections (main, AuxK, multi-top-k), losses and
+    every gradient -- W_skip's replicated, b_dec's summed over the shards."""
+    from sparsify_amd import SparseCoderConfig, parallel
+    from sparsify_amd.sharded import ShardedSparseCoder
+
+    N, D, M, k = 160, 64, 1024, 12
+    alpha = 1 / 32
+    auxk = variant in ("auxk", "auxk_few_dead", "all")
+    multi = variant in ("multi_topk", "all")
+    skip = variant in ("skip", "all")
+    transcode = skip                                   # the reference ties the skip connection to transcoders
+    fw = FakeWorld(W)
+    for name in ("rank", "world_size", "shard_range", "all_reduce_", "gather_topk_candidates"):
+        monkeypatch.setattr(parallel, name, getattr(fw, name))
+    cfg = SparseCoderConfig(num_latents=M, k=k, transcode=transcode, multi_topk=multi, skip_connection=skip)
+    P = O.init_params(D, M, transcode=transcode, seed=7)
+    g = torch.Generator().manual_seed(8)
+    P["b_enc"] = 0.05 * torch.randn(M, generator=g)
+    P["b_dec"] = 0.3 * torch.randn(D, generator=g)
+    if transcode:
+        P["W_dec"] = torch.randn(M, D, generator=g) / D**0.5
+    if skip:
+        P["W_skip"] = torch.randn(D, D, generator=g) * 0.05
+    x = torch.randn(N, D, generator=g) + torch.randn(D, generator=g)
+    y = x @ (torch.randn(D, D, generator=g) / D**0.5) if transcode else None
+    dead = None
+    if auxk:
+        dead = torch.zeros(M, dtype=torch.bool)
+        if variant == "auxk_few_dead":
+            dead[torch.randperm(M, generator=g)[:20]] = True          # fewer than k_aux = D / 2 = 32
+            dead[M // W - 1] = dead[M // W] = True                    # on both sides of a shard boundary
+        else:
+            dead[torch.rand(M, generator=g) < 0.3] = True
+    ocfg = O.OracleConfig(k=k, transcode=transcode, multi_topk=multi)
+    ref, G = O.forward_backward(P, x, y, ocfg, dead_mask=dead, auxk_alpha=alpha if auxk else 0.0)
+
+    results, errors = [None] * W, []
+    Pg = {n: t.cuda() for n, t in P.items()}
+    xg, yg, dg = x.cuda(), (None if y is None else y.cuda()), (None if dead is None else dead.cuda())
+
+    def worker(r):
+        try:
+            fw.local.rank = r
+            torch.cuda.set_device(0)
+            own_stream(torch)
+            lo, hi = fw.shard_range(M)
+            sh = ShardedSparseCoder(D, cfg, device="cuda")
+            with torch.no_grad():
+                sh.encoder.weight.copy_(Pg["W_enc"][lo:hi]); sh.encoder.bias.copy_(Pg["b_enc"][lo:hi])
+                sh.W_dec.copy_(Pg["W_dec"][lo:hi]); sh.b_dec.copy_(Pg["b_dec"])
+                if skip:
+                    sh.W_skip.copy_(Pg["W_skip"])
+            with torch.autocast("cuda", enabled=False):
+                out = type(sh).forward.__wrapped__(sh, xg, yg, dead_mask=dg)
+            (out.fvu + alpha * out.auxk_loss + out.multi_topk_fvu / 8).backward()
+            torch.cuda.synchronize()
+            results[r] = (out, sh, lo, hi)
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+            fw.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not errors, errors
+
+    bdec_grad = sum(r[1].b_dec.grad for r in results).cpu()
+    for out, sh, lo, hi in results:
+        got_idx = out.latent_indices.cpu()
+        assert torch.equal(got_idx.sort(-1).values, ref["latent_indices"].sort(-1).values)
+        order_g, order_r = got_idx.argsort(-1), ref["latent_indices"].argsort(-1)
+        torch.testing.assert_close(out.latent_acts.detach().cpu().gather(-1, order_g),
+                                   ref["latent_acts"].gather(-1, order_r), rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(out.sae_out.detach().cpu(), ref["sae_out"], rtol=2e-4, atol=1e-4)
+        for key in ("fvu", "auxk_loss", "multi_topk_fvu"):
+            torch.testing.assert_close(float(getattr(out, key).detach()), float(ref[key]), rtol=2e-4, atol=1e-6)
+        if auxk:
+            assert float(ref["auxk_loss"]) > 0
+        grads = {"W_enc": sh.encoder.weight.grad.cpu(), "b_enc": sh.encoder.bias.grad.cpu(), "W_dec": sh.W_dec.grad.cpu()}
+        for name, gr in grads.items():
+            want = G[name][lo:hi]
+            rel = (gr - want).norm() / want.norm().clamp_min(1e-12)
+            assert rel < 2e-4, f"{name}[{lo}:{hi}]: relative error {rel:.3e}"
+        if skip:
+            rel = (sh.W_skip.grad.cpu() - G["W_skip"]).norm() / G["W_skip"].norm()
+            assert rel < 2e-4, f"W_skip: relative error {rel:.3e}"
+    assert (bdec_grad - G["b_dec"]).norm() / G["b_dec"].norm() < 2e-4
