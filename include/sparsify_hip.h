@@ -324,14 +324,19 @@ int sphip_segmented_weight_grad_schedulefree(const uint32_t* perm, const int32_t
  *                                  gradient; sparse_coder.py:281-295 + sign)
  *   sphip_apply_signs:             p -= lr * signs (optionally refreshing a bf16 shadow of p)
  *   sphip_decoder_apply_signs:     the same per decoder row, followed by the row
- *                                  normalisation when renorm != 0 (sparse_coder.py:273-279) */
+ *                                  normalisation when renorm != 0 (sparse_coder.py:273-279);
+ *                                  slice_major: NULL, or the [D/32][sm_rows][32] copy of the
+ *                                  whole matrix (sphip_slice_major_f32), of which W holds
+ *                                  rows [sm_row0, sm_row0 + M): the finished rows are written
+ *                                  there too (fused form only: renorm, D % 32 == 0) */
 int sphip_sign_i8(const float* g, int64_t n, int8_t* out, void* stream);
 int sphip_decoder_project_sign_i8(const float* W, const float* G, int64_t M, int64_t D,
                                   int8_t* out, void* stream);
 int sphip_apply_signs(float* p, const int8_t* signs, int64_t n, float lr, void* bf16_shadow,
                       void* stream);
 int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr,
-                              int renorm, void* stream);
+                              int renorm, float* slice_major, int64_t sm_rows, int64_t sm_row0,
+                              void* stream);
 /* The schedule-free step ("signum", see sphip_schedulefree_signsgd_step) with the exchanged
  * signs in place of sign(g): sign(mean gradient), for decoder rows of the projected mean
  * gradient (sphip_decoder_project_sign_i8 on the parameter y). Same arithmetic as the one-GPU
@@ -340,6 +345,7 @@ int sphip_schedulefree_apply_signs(float* p, float* z, const int8_t* signs, int6
                                    float beta, float c, void* bf16_shadow, void* stream);
 int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const int8_t* signs, int64_t M,
                                            int64_t D, float lr, float beta, float c, int renorm,
+                                           float* slice_major, int64_t sm_rows, int64_t sm_row0,
                                            void* stream);
 
 /* trainer.py:422: did_fire[idx.flatten()] = True.  did_fire (M) uint8. */

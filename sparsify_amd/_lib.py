@@ -69,14 +69,14 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_broadcast_rows": (_I, [_P, _L, _L, _P, _P]),
     "sphip_gather_rows_bf16": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
-    "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P]),
+    "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P, _L, _L, _P]),
     "sphip_segmented_weight_grad_signsgd": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _F, _P, _P, _Z, _P]),
     "sphip_segmented_weight_grad_schedulefree": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _P, _F, _F, _F, _P, _P, _Z, _P]),
     "sphip_segment_coeff_sums": (_I, [_P, _P, _P, _I, _L, _P, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),
     "sphip_apply_signs": (_I, [_P, _P, _L, _F, _P, _P]),
-    "sphip_decoder_apply_signs": (_I, [_P, _P, _L, _L, _F, _I, _P]),
+    "sphip_decoder_apply_signs": (_I, [_P, _P, _L, _L, _F, _I, _P, _L, _L, _P]),
     "sphip_mark_fired": (_I, [_P, _L, _L, _P, _P]),
     "sphip_dead_counter_step": (_I, [_P, _P, _L, _L, _P]),
     "sphip_dead_mask": (_I, [_P, _L, _L, _P, _P, _P]),

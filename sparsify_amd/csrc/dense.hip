@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void apply_signs_kernel(float* __restrict__ p,
 // decoder_row_resident_kernel<R, 2>, so the data-parallel step equals the single-GPU one)
 template <int R>
 __global__ __launch_bounds__(256) void apply_signs_norm_kernel(float* __restrict__ W, const signed char* __restrict__ sg,
-                                                               int D, float lr, float eps) {
+                                                               int D, float lr, float eps, float* __restrict__ sm,
+                                                               int64_t sm_rows, int64_t sm_row0) {
     __shared__ float red[16];
     float* w = W + (int64_t)blockIdx.x * D;
     const signed char* t = sg + (int64_t)blockIdx.x * D;
@@ -362,6 +363,11 @@ __global__ __launch_bounds__(256) void apply_signs_norm_kernel(float* __restrict
         if (c < D) {
             b[i].x /= denom; b[i].y /= denom; b[i].z /= denom; b[i].w /= denom;
             *reinterpret_cast<float4*>(w + c) = b[i];
+            // the slice-major copy [D/32][sm_rows][32] of the whole matrix, of which W holds the
+            // rows from sm_row0 on (a row block of the data-parallel exchange)
+            const int c4 = c >> 2;
+            if (sm != nullptr)
+                *reinterpret_cast<float4*>(sm + (((int64_t)(c4 >> 3) * sm_rows + sm_row0 + blockIdx.x) * 8 + (c4 & 7)) * 4) = b[i];
         }
     }
 }
@@ -535,7 +541,8 @@ template <int R>
 __global__ __launch_bounds__(256) void sf_decoder_apply_signs_kernel(float* __restrict__ W, float* __restrict__ Z,
                                                                      const signed char* __restrict__ sg, int D, float lr,
                                                                      float w_undo, float c, float w_y, int renorm,
-                                                                     float eps) {
+                                                                     float eps, float* __restrict__ sm, int64_t sm_rows,
+                                                                     int64_t sm_row0) {
     __shared__ float red[16];
     float* w = W + (int64_t)blockIdx.x * D;
     float* zr = Z + (int64_t)blockIdx.x * D;
@@ -571,6 +578,9 @@ __global__ __launch_bounds__(256) void sf_decoder_apply_signs_kernel(float* __re
         if (col < D) {
             *reinterpret_cast<float4*>(w + col) = y[i];
             *reinterpret_cast<float4*>(zr + col) = z[i];
+            const int c4 = col >> 2;
+            if (sm != nullptr)
+                *reinterpret_cast<float4*>(sm + (((int64_t)(c4 >> 3) * sm_rows + sm_row0 + blockIdx.x) * 8 + (c4 & 7)) * 4) = y[i];
         }
     }
 }
@@ -719,22 +729,29 @@ extern "C" int sphip_apply_signs(float* p, const int8_t* signs, int64_t n, float
     return SPHIP_OK;
 }
 
-extern "C" int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr, int renorm, void* stream) {
+extern "C" int sphip_decoder_apply_signs(float* W, const int8_t* signs, int64_t M, int64_t D, float lr, int renorm,
+                                         float* slice_major, int64_t sm_rows, int64_t sm_row0, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W && signs, SPHIP_EINVAL, "decoder_apply_signs: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "decoder_apply_signs: bad shape");
+    SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0 && sm_row0 >= 0 &&
+                                             sm_row0 + M <= sm_rows),
+                  SPHIP_EINVAL, "decoder_apply_signs: the slice-major copy needs D %% 32 == 0, a 16-byte aligned buffer and "
+                  "rows [%lld, %lld) inside its %lld rows", (long long)sm_row0, (long long)(sm_row0 + M), (long long)sm_rows);
     hipStream_t s = (hipStream_t)stream;
     const signed char* t = (const signed char*)signs;
     const bool vec = D % 4 == 0 && D <= 8192 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)signs & 3) == 0;
     if (renorm && vec) {
         dim3 grid((unsigned)M), block(256);
-        if (D <= 1024) hipLaunchKernelGGL((apply_signs_norm_kernel<1>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
-        else if (D <= 2048) hipLaunchKernelGGL((apply_signs_norm_kernel<2>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
-        else if (D <= 4096) hipLaunchKernelGGL((apply_signs_norm_kernel<4>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
-        else hipLaunchKernelGGL((apply_signs_norm_kernel<8>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS);
+        if (D <= 1024) hipLaunchKernelGGL((apply_signs_norm_kernel<1>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+        else if (D <= 2048) hipLaunchKernelGGL((apply_signs_norm_kernel<2>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+        else if (D <= 4096) hipLaunchKernelGGL((apply_signs_norm_kernel<4>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+        else hipLaunchKernelGGL((apply_signs_norm_kernel<8>), grid, block, 0, s, W, t, (int)D, lr, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
         SPHIP_CHECK_LAUNCH("decoder_apply_signs");
         return SPHIP_OK;
     }
+    SPHIP_REQUIRE(slice_major == nullptr, SPHIP_EUNSUPPORTED,
+                  "decoder_apply_signs: the slice-major copy is written by the fused form only (renorm, D %% 4 == 0, D <= 8192)");
     const int st = sphip_apply_signs(W, signs, M * D, lr, nullptr, stream);
     if (st != SPHIP_OK || !renorm) return st;
     return sphip_unit_norm_rows(W, M, D, stream);
@@ -797,9 +814,15 @@ extern "C" int sphip_schedulefree_apply_signs(float* p, float* z, const int8_t* 
 }
 
 extern "C" int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const int8_t* signs, int64_t M, int64_t D,
-                                                      float lr, float beta, float c, int renorm, void* stream) {
+                                                      float lr, float beta, float c, int renorm, float* slice_major,
+                                                      int64_t sm_rows, int64_t sm_row0, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W && Z && signs, SPHIP_EINVAL, "decoder_schedulefree_apply_signs: null pointer");
+    SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0 && sm_row0 >= 0 &&
+                                             sm_row0 + M <= sm_rows),
+                  SPHIP_EINVAL, "decoder_schedulefree_apply_signs: the slice-major copy needs D %% 32 == 0, a 16-byte aligned "
+                  "buffer and rows [%lld, %lld) inside its %lld rows", (long long)sm_row0, (long long)(sm_row0 + M),
+                  (long long)sm_rows);
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
                   "decoder_schedulefree_apply_signs: bad shape / beta");
     SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
@@ -809,9 +832,9 @@ extern "C" int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const 
     dim3 grid((unsigned)M), block(256);
     const float wu = 1.f - 1.f / beta, wy = 1.f - beta;
     const signed char* t = (const signed char*)signs;
-    if (D <= 1024) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<1>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
-    else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<2>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
-    else hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<4>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    if (D <= 1024) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<1>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+    else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<2>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+    else hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<4>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
     SPHIP_CHECK_LAUNCH("decoder_schedulefree_apply_signs");
     return SPHIP_OK;
 }

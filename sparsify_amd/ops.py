@@ -696,14 +696,30 @@ def apply_signs_(p: Tensor, signs: Tensor, lr: float, bf16_shadow: Tensor | None
     return p
 
 
-def decoder_apply_signs_(W: Tensor, signs: Tensor, lr: float, renorm: bool = False) -> Tensor:
-    """W -= lr * signs per decoder row; renorm=True also re-normalises the updated rows."""
+def _sm_args(slice_major: Tensor | None, W: Tensor, row0: int, name: str):
+    """(pointer, rows, first row) of the slice-major copy a row block W belongs to."""
+    if slice_major is None:
+        return None, 0, 0
+    _req(slice_major, "slice_major", torch.float32)
+    D = W.shape[1]
+    if D % 32 or slice_major.numel() % D or row0 < 0 or row0 + W.shape[0] > slice_major.numel() // D:
+        raise ValueError(f"{name}: slice_major must hold whole rows of D = {D} floats (D % 32 == 0) covering "
+                         f"rows [{row0}, {row0 + W.shape[0]})")
+    return slice_major.data_ptr(), slice_major.numel() // D, row0
+
+
+def decoder_apply_signs_(W: Tensor, signs: Tensor, lr: float, renorm: bool = False,
+                         slice_major: Tensor | None = None, row0: int = 0) -> Tensor:
+    """W -= lr * signs per decoder row; renorm=True also re-normalises the updated rows.
+    slice_major / row0: the [D/32][rows][32] copy of the whole matrix and W's first row in it; the
+    finished rows are written there in the same pass (renorm only)."""
     _req(W, "W_dec", torch.float32, 2)
     _req(signs, "signs", torch.int8)
     if signs.numel() != W.numel():
         raise ValueError("decoder_apply_signs: size mismatch")
+    sm, rows, r0 = _sm_args(slice_major, W, row0, "decoder_apply_signs")
     check(_lib.load().sphip_decoder_apply_signs(W.data_ptr(), signs.data_ptr(), W.shape[0], W.shape[1], float(lr),
-                                               int(renorm), _stream(W)), "sphip_decoder_apply_signs")
+                                               int(renorm), sm, rows, r0, _stream(W)), "sphip_decoder_apply_signs")
     return W
 
 
@@ -724,15 +740,16 @@ def schedulefree_apply_signs_(p: Tensor, z: Tensor, signs: Tensor, lr: float, be
 
 
 def decoder_schedulefree_apply_signs_(W: Tensor, Z: Tensor, signs: Tensor, lr: float, beta: float, c: float,
-                                      renorm: bool = False) -> Tensor:
+                                      renorm: bool = False, slice_major: Tensor | None = None, row0: int = 0) -> Tensor:
     _req(W, "W_dec", torch.float32, 2)
     _req(Z, "z", torch.float32, 2)
     _req(signs, "signs", torch.int8)
     if signs.numel() != W.numel() or Z.shape != W.shape:
         raise ValueError("decoder_schedulefree_apply_signs: size mismatch")
+    sm, rows, r0 = _sm_args(slice_major, W, row0, "decoder_schedulefree_apply_signs")
     check(_lib.load().sphip_decoder_schedulefree_apply_signs(W.data_ptr(), Z.data_ptr(), signs.data_ptr(), W.shape[0],
                                                             W.shape[1], float(lr), float(beta), float(c), int(renorm),
-                                                            _stream(W)), "sphip_decoder_schedulefree_apply_signs")
+                                                            sm, rows, r0, _stream(W)), "sphip_decoder_schedulefree_apply_signs")
     return W
 
 

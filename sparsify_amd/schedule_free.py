@@ -189,9 +189,11 @@ class ScheduleFreeWrapper:
         from .fused_encoder import peek_bf16_shadow, register_bf16_shadow
         w, beta = p.data, self.momentum
         shadow = None if project else peek_bf16_shadow(p)
+        sm = ops.peek_slice_major(p) if project and p.shape[1] % 32 == 0 else None        # as SignSGD._exchange_step
         if project:
             def apply_fn(signs, lo, hi):
-                ops.decoder_schedulefree_apply_signs_(w[lo:hi], z[lo:hi], signs, lr, beta, c, renorm)
+                ops.decoder_schedulefree_apply_signs_(w[lo:hi], z[lo:hi], signs, lr, beta, c, renorm,
+                                                      slice_major=sm, row0=lo)
         else:
             def apply_fn(signs, lo, hi):
                 ops.schedulefree_apply_signs_(w[lo:hi], z[lo:hi], signs, lr, beta, c,
@@ -201,6 +203,8 @@ class ScheduleFreeWrapper:
             self.base.renormalised.add(id(p))
         if shadow is not None:
             register_bf16_shadow(p, shadow)
+        if sm is not None:
+            ops.register_slice_major(p, sm)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -145,9 +145,12 @@ class SignSGD(Optimizer):
         """One large matrix under data parallelism: see parallel.SignExchange."""
         w = p.data
         shadow = None if project else peek_bf16_shadow(p)
+        # the slice-major copy the L2-resident decode reads is rewritten row block by row block by
+        # the kernel that applies the signs (fused form: with the re-normalisation)
+        sm = ops.peek_slice_major(p) if project and renorm and p.shape[1] % 32 == 0 and p.shape[1] <= 8192 else None
         if project:
             def apply_fn(signs, lo, hi):
-                ops.decoder_apply_signs_(w[lo:hi], signs, lr, renorm)
+                ops.decoder_apply_signs_(w[lo:hi], signs, lr, renorm, slice_major=sm, row0=lo)
         else:
             def apply_fn(signs, lo, hi):
                 ops.apply_signs_(w[lo:hi], signs, lr, None if shadow is None else shadow[lo:hi])
@@ -157,6 +160,8 @@ class SignSGD(Optimizer):
                 self.renormalised.add(id(p))
             if shadow is not None:
                 register_bf16_shadow(p, shadow)
+            if sm is not None:
+                ops.register_slice_major(p, sm)
         return events
 
     def run_exchange(self, p, g, project: bool, apply_fn, overlap: bool, rows=None, prior=None, finish: bool = True):

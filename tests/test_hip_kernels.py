@@ -764,3 +764,34 @@ def test_schedulefree_decoder_step_writes_the_slice_major_copy(device, D, renorm
     ops.decoder_schedulefree_signsgd_step_(Wg, Zg, G, 3e-3, 0.95, 0.25, renorm, slice_major=buf)
     assert torch.equal(Wg, Wp) and torch.equal(Zg, Zp)
     assert torch.equal(buf, Wg.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
+
+
+@pytest.mark.parametrize("schedule_free", [False, True])
+def test_apply_signs_by_row_blocks_writes_the_slice_major_copy(device, schedule_free):
+    """The data-parallel decoder step (sphip_decoder_apply_signs / ..._schedulefree_apply_signs) run
+    row block by row block with the slice-major buffer of the whole matrix: parameters bit for
+    bit those of the call without the buffer, the buffer the slice-major form of the result."""
+    from sparsify_amd import ops
+    M, D = 1000, 1024
+    g = torch.Generator(device="cuda").manual_seed(3)
+    W0 = torch.randn(M, D, device="cuda", generator=g)
+    W0 /= W0.norm(dim=1, keepdim=True)
+    Z0 = W0 + 0.01 * torch.randn(M, D, device="cuda", generator=g)
+    signs = torch.randint(-1, 2, (M, D), device="cuda", generator=g, dtype=torch.int8)
+    Wp, Zp = W0.clone(), Z0.clone()
+    if schedule_free:
+        ops.decoder_schedulefree_apply_signs_(Wp, Zp, signs, 3e-3, 0.95, 0.25, True)
+    else:
+        ops.decoder_apply_signs_(Wp, signs, 3e-3, True)
+    Wg, Zg = W0.clone(), Z0.clone()
+    buf = torch.full((D // 32, M, 32), float("nan"), device="cuda")
+    for lo, hi in ((0, 256), (256, 700), (700, M)):
+        if schedule_free:
+            ops.decoder_schedulefree_apply_signs_(Wg[lo:hi], Zg[lo:hi], signs[lo:hi], 3e-3, 0.95, 0.25, True,
+                                                  slice_major=buf, row0=lo)
+        else:
+            ops.decoder_apply_signs_(Wg[lo:hi], signs[lo:hi], 3e-3, True, slice_major=buf, row0=lo)
+    assert torch.equal(Wg, Wp) and torch.equal(Zg, Zp)
+    assert torch.equal(buf, Wg.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
+    with pytest.raises(ValueError):
+        ops.decoder_apply_signs_(Wg[0:10], signs[0:10], 3e-3, True, slice_major=buf, row0=M - 5)
