@@ -2,7 +2,8 @@
 Usage: python benchmarks/gemm_bench.py [diag ...]   (diag = SPHIP_GEMM_DIAG values to sweep; non-zero
 values need a library built with `make -C sparsify_amd/csrc clean all DIAG=1`; "lib" = the vendor
 library's GEMM alone through torch, F.linear without bias or ReLU, "libref" = what the reference
-launches, relu(F.linear(x, W, b)), both for comparison only)"""
+launches, relu(F.linear(x, W, b)), both for comparison only; "s0" / "s1" = SPHIP_GEMM_SCHED 0 / 1 of
+the shipped kernel, whose outputs are also compared bit for bit over repeated launches)"""
 import os
 import sys
 
@@ -22,6 +23,10 @@ res = {dg: [] for dg in diags}
 
 
 def launch(dg):
+    if dg in ("s0", "s1"):
+        os.environ["SPHIP_GEMM_DIAG"] = "0"
+        os.environ["SPHIP_GEMM_SCHED"] = dg[1]
+        return ops.encoder_preacts(x, W, b)
     if dg == "lib":
         return torch.nn.functional.linear(x, W)
     if dg == "libref":
@@ -31,7 +36,7 @@ def launch(dg):
 
 for rnd in range(3):                      # interleaved rounds: variants share the device's state
     for dg in diags:
-        if not dg.startswith("lib"):
+        if not dg.startswith("lib") and dg not in ("s0", "s1"):
             os.environ["SPHIP_GEMM_DIAG"] = dg
         launch(dg)
         torch.cuda.synchronize()
@@ -46,3 +51,11 @@ for dg, v in res.items():
     v = sorted(v)
     ms = v[len(v) // 2]
     print(f"diag={dg} median {ms:.3f} ms (min {v[0]:.3f})  {2.0 * N * D * M / ms / 1e9:.0f} TFLOP/s", flush=True)
+if "s0" in diags and "s1" in diags:
+    b.copy_((torch.randn(M, device=dev, generator=g) * 0.1).to(torch.bfloat16))
+    ref = launch("s0")
+    bad = 0
+    for i in range(6):
+        got = launch("s1" if i % 2 == 0 else "s0")
+        bad += int((got.view(torch.int16) != ref.view(torch.int16)).sum())
+    print(f"s0 / s1 bitwise over 6 launches: {bad} differing elements", flush=True)

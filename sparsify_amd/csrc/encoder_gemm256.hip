@@ -41,6 +41,7 @@ constexpr int G_TILE = 256;
 // release latency under the last MFMAs). A/B on one box, interleaved, with the non-temporal
 // epilogue stores: 0 -> 12.27 ms, 1 -> 12.02 ms (2 was slower: 12.6 against 12.1 ms earlier)
 constexpr int EARLY = 1;
+constexpr int G_SCHED_DEFAULT = 0;            // see SCHED at gemm256_tile
 constexpr int G_BK = 64;                      // bf16 elements per K tile (128 B)
 constexpr int R_X = 0;                        // region offsets inside a K-tile buffer
 constexpr int R_WLO = 256 * 128;              // 32 KiB
@@ -82,7 +83,15 @@ struct EmitArgs {
 // be null), the Newton-Schulz products of Muon (sphip_gemm_bf16_axpy, encoder_gemm.hip);
 // 4 = the encoder's values are not stored: every 16-byte chunk (8 latents) of a token that holds a
 // value above the token's threshold is appended to the token's candidate list.
-template <bool RELU, int DIAG, int OUTF>
+// SCHED: 0 = the staging DMA is issued between the MFMAs of the M segments (header above);
+// 1 = it is issued in the L segments, behind the segment's fragment reads: the wave that issues
+// it is then the one waiting at the barrier while its SIMD partner runs MFMAs, so the M segments
+// are bare MFMA chains. W-hi(t+1) goes out in L0(t), X(t+2) / W-lo(t+2) in L1(t), each one
+// segment earlier than under SCHED 0 (code segment r + 2 instead of r + 3 after the last read of
+// the region in segment r): the L segments therefore complete their fragment reads (lgkmcnt(0))
+// BEFORE their closing barrier, so that when the leading group enters segment r + 2 the lagging
+// group has passed the barrier closing its segment r with its reads done.
+template <bool RELU, int DIAG, int OUTF, int SCHED = 0>
 __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                              const bf16_t* __restrict__ bias, bf16_t* __restrict__ P, int N, int D,
                                              int M, int tm, int tn, bf16_t* __restrict__ tile_max, int64_t ldp,
@@ -259,15 +268,16 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
             { const unsigned a0 = xbase[0] + bo, a1 = xbase[1] + bo; SPHIP_READ4(xf, R_X); }    \
             { const unsigned a0 = wbase[0] + bo, a1 = wbase[1] + bo; SPHIP_READ4(wf, R_WLO); }  \
         }                                                                                       \
+        if (SCHED == 1 && (ISSUE_HI) && !(DIAG & 1)) stage_w(1, t + 1);                         \
         WAIT_L0;                                                                                \
+        if (SCHED == 1) { SPHIP_LGKM0(xf); SPHIP_LGKM0(wf); }                                   \
         SPHIP_STAMP(0)                                                                          \
         seg_barrier();                                                                          \
         SPHIP_STAMP(1)                                                                          \
         /* M0 */                                                                                \
-        SPHIP_LGKM0(xf);                                                                        \
-        SPHIP_LGKM0(wf);                                                                        \
+        if (SCHED == 0) { SPHIP_LGKM0(xf); SPHIP_LGKM0(wf); }                                   \
         SPHIP_STAMP(2)                                                                          \
-        mma(0, ((ISSUE_HI) && !(DIAG & 1)) ? 2 : 0, [&](int j) { stage_w1(1, t + 1, j); });       \
+        mma(0, (SCHED == 0 && (ISSUE_HI) && !(DIAG & 1)) ? 2 : 0, [&](int j) { stage_w1(1, t + 1, j); }); \
         SPHIP_STAMP(3)                                                                          \
         SPHIP_STAMP(4)                                                                          \
         /* L1 */                                                                                \
@@ -275,14 +285,16 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
             const unsigned a0 = wbase[0] + bo, a1 = wbase[1] + bo;                              \
             SPHIP_READ4(wf, R_WHI);                                                             \
         }                                                                                       \
+        if (SCHED == 1 && (ISSUE_X) && !(DIAG & 1)) { stage_x(t + 2); stage_w(0, t + 2); }      \
         WAIT_L1;                                                                                \
+        if (SCHED == 1) { SPHIP_LGKM0(wf); }                                                    \
         SPHIP_STAMP(5)                                                                          \
         seg_barrier();                                                                          \
         SPHIP_STAMP(6)                                                                          \
         /* M1 */                                                                                \
-        SPHIP_LGKM0(wf);                                                                        \
+        if (SCHED == 0) { SPHIP_LGKM0(wf); }                                                    \
         SPHIP_STAMP(7)                                                                          \
-        mma(4, ((ISSUE_X) && !(DIAG & 1)) ? 6 : 0, [&](int j) {                                  \
+        mma(4, (SCHED == 0 && (ISSUE_X) && !(DIAG & 1)) ? 6 : 0, [&](int j) {                   \
             if (j < 4) stage_x1(t + 2, j);                                                      \
             else stage_w1(0, t + 2, j - 4);                                                     \
         });                                                                                     \
@@ -290,11 +302,21 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
         SPHIP_STAMP(9)                                                                          \
     }
 
+    // outstanding DMA per wave at the two waits under SCHED 1 (the segment's own issue included):
+    //   L0: [W-hi(t) 2][X(t+1) 4][W-lo(t+1) 2][W-hi(t+1) 2]   L1: [X(t+1) 4][W-lo(t+1) 2][W-hi(t+1) 2][X(t+2) 4][W-lo(t+2) 2]
     int t = 0;
+    if (SCHED == 1) {
+        for (; t < kTiles - 2; ++t) SPHIP_KTILE(true, true, SPHIP_VMCNT(8), SPHIP_VMCNT(8))
+        if (kTiles > 1) {
+            SPHIP_KTILE(true, false, SPHIP_VMCNT(8), SPHIP_VMCNT(2))
+            ++t;
+        }
+    } else {
     for (; t < kTiles - 2; ++t) SPHIP_KTILE(true, true, SPHIP_VMCNT(6), SPHIP_VMCNT(2))
     if (kTiles > 1) {
         SPHIP_KTILE(true, false, SPHIP_VMCNT(6), SPHIP_VMCNT(2))
         ++t;
+    }
     }
     SPHIP_KTILE(false, false, SPHIP_VMCNT(0), (void)0)
 #undef SPHIP_KTILE
@@ -361,22 +383,34 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
     // staging image is dead after the barrier above) and leaves as 256-B row segments.
     char* epi = smem + wave * EPI_WAVE;
     float bv[8][4];
-    {
-        const bool bvec = (((uintptr_t)bias & 7) == 0);
+    // The lane's bias values (4 consecutive latents for each of its 8 accumulator rows). With an
+    // 8-byte aligned bias and M % 4 == 0 they arrive as eight 8-byte buffer loads issued back to
+    // back (one round trip; the descriptor returns zeros for latents past M); the element-wise
+    // form branches around every load and waits for each in turn (eight dependent round trips per tile).
+    if (bias != nullptr && (((uintptr_t)bias & 7) == 0) && (M & 3) == 0) {
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, M * 2, 0x00020000);
+        typedef unsigned bu2_t __attribute__((ext_vector_type(2)));
+        bu2_t raw[8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
+            raw[mi] = __builtin_amdgcn_raw_buffer_load_b64(brsrc, m * 2, 0, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            bv[mi][0] = __uint_as_float(raw[mi][0] << 16), bv[mi][1] = __uint_as_float(raw[mi][0] & 0xffff0000u);
+            bv[mi][2] = __uint_as_float(raw[mi][1] << 16), bv[mi][3] = __uint_as_float(raw[mi][1] & 0xffff0000u);
+        }
+    } else {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + wm * 128 + (mi >> 2) * 64 + (mi & 3) * 16 + q4 * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[mi][j] = 0.f;
             if (bias == nullptr) continue;
-            if (bvec && m + 3 < M) {
-                const float4 b4 = load4(bias + m);
-                bv[mi][0] = b4.x, bv[mi][1] = b4.y, bv[mi][2] = b4.z, bv[mi][3] = b4.w;
-            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (m + j < M) bv[mi][j] = bf16_to_f32(bias[m + j]);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (m + j < M) bv[mi][j] = bf16_to_f32(bias[m + j]);
         }
     }
 #pragma unroll
@@ -509,7 +543,7 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
 // One workgroup per tile, or (gridDim.x < nTiles, a multiple of 8) a resident workgroup per CU
 // walking its XCD's tiles: virtual block vb = blockIdx.x + i * gridDim.x keeps vb & 7 = the XCD
 // the workgroup runs on, so the XCD-contiguous tile ranges below are the same in both forms.
-template <bool RELU, int DIAG = 0, int OUTF = 0>
+template <bool RELU, int DIAG = 0, int OUTF = 0, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* __restrict__ X,
                                                                  const bf16_t* __restrict__ W,
                                                                  const bf16_t* __restrict__ bias,
@@ -530,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void encoder_gemm256_kernel(const bf16_t* _
         const unsigned g = L / band, within = L % band;
         const unsigned first = g * (unsigned)bandh;
         const unsigned gsize = min((unsigned)tilesM - first, (unsigned)bandh);
-        gemm256_tile<RELU, DIAG, OUTF>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
+        gemm256_tile<RELU, DIAG, OUTF, SCHED>(X, W, bias, P, N, D, M, (int)(first + within % gsize), (int)(within / gsize),
                                        tile_max, ldp, tilesT, dbg, smem, alpha, beta, ea);
         if (vb + gridDim.x < nb) __syncthreads();      // the next tile's staging overwrites the epilogue area
     }
@@ -562,14 +596,21 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
     const int tilesM = (int)cdiv(M, G_TILE), tilesN = (int)cdiv(N, G_TILE);
     const int64_t nblocks = (int64_t)tilesM * tilesN;
     if (nblocks >= (1ll << 31)) return false;
-    static bool attr_set[2] = {false, false};
-    const void* fn = relu ? (const void*)encoder_gemm256_kernel<true> : (const void*)encoder_gemm256_kernel<false>;
-    if (!attr_set[relu ? 1 : 0]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES) != hipSuccess) {
+    // SPHIP_GEMM_SCHED (A/B switch, read per call): where the staging DMA is issued, see SCHED above
+    const char* sc = getenv("SPHIP_GEMM_SCHED");
+    const int sched = sc ? (atoi(sc) == 1 ? 1 : 0) : G_SCHED_DEFAULT;
+    typedef void (*kern_t)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, int, bf16_t*,
+                           int64_t, int, int, unsigned*, float, float, EmitArgs);
+    static const kern_t kerns[2][2] = {{encoder_gemm256_kernel<false, 0, 0, 0>, encoder_gemm256_kernel<false, 0, 0, 1>},
+                                       {encoder_gemm256_kernel<true, 0, 0, 0>, encoder_gemm256_kernel<true, 0, 0, 1>}};
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    const kern_t fn = kerns[relu ? 1 : 0][sched];
+    if (!attr_set[relu ? 1 : 0][sched]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        attr_set[relu ? 1 : 0] = true;
+        attr_set[relu ? 1 : 0][sched] = true;
     }
     // SPHIP_GEMM_PERSIST=n: n resident workgroups per CU-count of 256 walk the tiles (A/B switch)
     const char* pers = getenv("SPHIP_GEMM_PERSIST");
@@ -590,7 +631,11 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
         hipLaunchKernelGGL((encoder_gemm256_kernel<true, DG>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,       \
                            (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(), dbgp); \
     }
-    if (diag == 1) SPHIP_DIAG_LAUNCH(1)
+    if (diag == 32 && sched == 1) {
+        (void)hipFuncSetAttribute((const void*)encoder_gemm256_kernel<true, 32, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+        hipLaunchKernelGGL((encoder_gemm256_kernel<true, 32, 0, 1>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x,
+                           (const bf16_t*)W, (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(), dbgp);
+    } else if (diag == 1) SPHIP_DIAG_LAUNCH(1)
     else if (diag == 2) SPHIP_DIAG_LAUNCH(2)
     else if (diag == 3) SPHIP_DIAG_LAUNCH(3)
     else if (diag == 4) SPHIP_DIAG_LAUNCH(4)
@@ -614,14 +659,9 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
     else if (diag == 256) SPHIP_DIAG_LAUNCH(256)
     else
 #endif
-    if (relu)
-        hipLaunchKernelGGL((encoder_gemm256_kernel<true>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(),
-                           (unsigned*)nullptr, 1.f, 0.f, ea);
-    else
-        hipLaunchKernelGGL((encoder_gemm256_kernel<false>), grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W,
-                           (const bf16_t*)bias, (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT, gemm_band(),
-                           (unsigned*)nullptr, 1.f, 0.f, ea);
+    hipLaunchKernelGGL(fn, grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)bias,
+                       (bf16_t*)pre, (int)N, (int)D, (int)M, tilesM, tilesN, (bf16_t*)tile_max, ldp, (int)tilesT,
+                       gemm_band(), (unsigned*)nullptr, 1.f, 0.f, ea);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("encoder_preacts(256): launch failed: %s", hipGetErrorString(e));

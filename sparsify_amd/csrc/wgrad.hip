@@ -243,9 +243,14 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             float d = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c) d = fmaf(v[u][c], wdot[c], d);
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
+            // sum over the 8 lanes of the group with DPP moves (quad xor 1, quad xor 2, half-row
+            // mirror) instead of three ds_bpermute round trips through the LDS pipe per entry; the
+            // quad sums are the same bits in all four lanes (commutative adds), so lane 7 - i
+            // delivers what lane i ^ 4 would: bit for bit the xor butterfly's result. A group's 8
+            // lanes enter and leave the loops together, so no lane reads a disabled one.
+            d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xF, 0xF, true));
+            d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xF, 0xF, true));
+            d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true));
             mine_d = (sub == u) ? d : mine_d;
         }
         if (sub < count && p + sub < stop) sl[p + sub] = mine_d;
