@@ -106,14 +106,38 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
     const int n0 = (int)(local % (unsigned)groups_per_slice) * 32;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
-    const int n = n0 + (threadIdx.x >> 6) * 8 + grp;
+    // The workgroup's 32 tokens are handed to the lane groups in order of list length (wave 0
+    // takes the 8 longest lists of this latent block): a wave lives as long as its longest list,
+    // and the lists of a (token, block) pair vary like a binomial around k / B. The sum of a
+    // token is unchanged (one lane group, list order).
+    __shared__ int sh_sb[33];
+    __shared__ int sh_ord[32];
+    if (threadIdx.x < 33) sh_sb[threadIdx.x] = (int)start[min(n0 + (int)threadIdx.x, N)];
+    __syncthreads();
+    {
+        const int i = threadIdx.x >> 3;                                // 8 lanes rank token i against 4 others each
+        const int mylen = sh_sb[i + 1] - sh_sb[i];
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = sub * 4 + q, l = sh_sb[o + 1] - sh_sb[o];
+            rank += (l > mylen || (l == mylen && o < i)) ? 1 : 0;
+        }
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0xB1, 0xF, 0xF, true);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x4E, 0xF, 0xF, true);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x141, 0xF, 0xF, true);
+        if (sub == 0) sh_ord[rank] = i;
+    }
+    __syncthreads();
+    const int nl = sh_ord[(threadIdx.x >> 6) * 8 + grp];
+    const int n = n0 + nl;
     const int col = (int)slice * 32 + sub * 4;
     const bool live = n < N;
     int beg = 0, end = 0;
-    if (live) { beg = (int)start[n]; end = (int)start[n + 1]; }
+    if (live) { beg = sh_sb[nl]; end = sh_sb[nl + 1]; }
 
     __shared__ uint2 sh[L2_STAGE];
-    const int rb = (int)start[n0], re = (int)start[min(n0 + 32, N)];     // block-uniform
+    const int rb = sh_sb[0], re = sh_sb[32];                             // block-uniform
     const bool staged = re - rb <= L2_STAGE;
     if (staged) {
         for (int i = threadIdx.x; i < re - rb; i += 256) sh[i] = list[rb + i];

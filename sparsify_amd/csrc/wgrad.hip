@@ -192,12 +192,46 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     const unsigned lblock = local % (unsigned)blocks_per_slice;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
-    const int j = (int)lblock * 32 + (threadIdx.x >> 6) * 8 + grp;
+    // Which of the workgroup's 32 consecutive latents a lane group reduces: a wave lives as long
+    // as the longest of its 8 segments (about 31 entries when the mean is 24), so the latents are
+    // handed out in order of segment length -- wave 0 takes the 8 longest, wave 3 the 8 shortest --
+    // and a wave's lane groups finish together. Every latent is still summed by one lane group in
+    // segment order: the sums do not change, only where they are computed.
+    __shared__ int sh_sb[33];
+    __shared__ int sh_ord[32];
+    if (threadIdx.x < 33) sh_sb[threadIdx.x] = seg_begin[min((int)lblock * 32 + (int)threadIdx.x, M)];
+    __syncthreads();
+#ifndef SPHIP_SLICED_SORT
+#define SPHIP_SLICED_SORT 1
+#endif
+    if (SPHIP_SLICED_SORT) {
+        auto eff_len = [&](int i) {
+            const int l = sh_sb[i + 1] - sh_sb[i];
+            return (skew != nullptr && l > skew_T) ? 0 : l;           // left to the wide kernel
+        };
+        const int i = threadIdx.x >> 3;                                // 8 lanes rank latent i against 4 others each
+        const int mylen = eff_len(i);
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = sub * 4 + q, l = eff_len(o);
+            rank += (l > mylen || (l == mylen && o < i)) ? 1 : 0;
+        }
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0xB1, 0xF, 0xF, true);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x4E, 0xF, 0xF, true);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x141, 0xF, 0xF, true);
+        if (sub == 0) sh_ord[rank] = i;
+    } else if (threadIdx.x < 32) {
+        sh_ord[threadIdx.x] = threadIdx.x;
+    }
+    __syncthreads();
+    const int jl = sh_ord[(threadIdx.x >> 6) * 8 + grp];
+    const int j = (int)lblock * 32 + jl;
     const int col = (int)slice * SLICE_COLS + sub * C;
     bool live = (j < M) && (col < D);
 
     int beg = 0, end = 0;
-    if (j < M) { beg = seg_begin[j]; end = seg_begin[j + 1]; }
+    if (j < M) { beg = sh_sb[jl]; end = sh_sb[jl + 1]; }
     const bool mine = skew == nullptr || end - beg <= skew_T;
     if (!mine) { beg = end = 0; live = false; }
     float acc[C];
@@ -266,8 +300,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // batch waited for). Ranges beyond the staging area (skewed latents) read global memory.
     constexpr int STAGE = 2048;                         // entries (16 KiB)
     __shared__ uint2 sh_pk[STAGE];
-    const int j0 = min((int)lblock * 32, M), j1 = min((int)lblock * 32 + 32, M);
-    const int rb = seg_begin[j0], re = seg_begin[j1];   // block-uniform
+    const int rb = sh_sb[0], re = sh_sb[32];            // block-uniform
     const bool staged = re - rb <= STAGE;
     if (staged) {
         for (int i = threadIdx.x; i < re - rb; i += 256) sh_pk[i] = packed[rb + i];
