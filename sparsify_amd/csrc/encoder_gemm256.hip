@@ -327,6 +327,13 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
         for (int i = 0; i < 10; ++i) o[i] = tacc[i];
     }
 
+    if (DIAG & 512) {                       // diagnostic: no epilogue at all (the accumulators stay live)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     if (OUTF == 3) {
         const int64_t ldc = tilesT;
 #pragma unroll
@@ -523,8 +530,8 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
             kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x4E, 0xF, 0xF, true));
             kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x141, 0xF, 0xF, true));
             kmax = max(kmax, (unsigned)__builtin_amdgcn_update_dpp(0, (int)kmax, 0x140, 0xF, 0xF, true));
-            if (chunk == 0 && n < N && m0 + wm * 128 < M)
-                tile_max[((int64_t)(n >> 6) * tilesT + ((m0 + wm * 128) >> 7)) * 64 + (n & 63)] = KeyOf<bf16_t>::value(kmax);
+            // parked in the token's pad; the wave's 64 maxima leave as one 128-byte line below
+            if (chunk == 0) *reinterpret_cast<unsigned short*>(epi + tok * EPI_ROW + 256) = KeyOf<bf16_t>::value(kmax);
         }
         if (n >= N || mcol >= M) continue;
         bf16_t* dst = P + (int64_t)n * ldp + mcol;
@@ -537,6 +544,15 @@ __device__ __forceinline__ void gemm256_tile(const bf16_t* __restrict__ X, const
             const unsigned w4[4] = {v.x, v.y, v.z, v.w};
             for (int j = 0; j < 8 && mcol + j < M; ++j) dst[j] = (bf16_t)(w4[j >> 1] >> ((j & 1) * 16));
         }
+    }
+    if (tile_max != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = n0 + wn * 64 + lane;                       // n0 + wn * 64 is a multiple of 64: (n & 63) == lane
+        if (n < N && m0 + wm * 128 < M)
+            tile_max[((int64_t)(n >> 6) * tilesT + ((m0 + wm * 128) >> 7)) * 64 + lane] =
+                *reinterpret_cast<const unsigned short*>(epi + lane * EPI_ROW + 256);
     }
 }
 
@@ -657,6 +673,7 @@ bool launch_gemm256_bf16(const void* x, const void* W, const void* bias, void* p
     else if (diag == 128) SPHIP_DIAG_LAUNCH(128)
     else if (diag == 192) SPHIP_DIAG_LAUNCH(192)
     else if (diag == 256) SPHIP_DIAG_LAUNCH(256)
+    else if (diag == 512) SPHIP_DIAG_LAUNCH(512)
     else
 #endif
     hipLaunchKernelGGL(fn, grid, block, G_LDS_BYTES, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)bias,
