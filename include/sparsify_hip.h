@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SPHIP_ABI_VERSION 2
+#define SPHIP_ABI_VERSION 3
 
 enum { SPHIP_F32 = 0, SPHIP_BF16 = 1 };
 enum { SPHIP_OK = 0, SPHIP_EINVAL = 1, SPHIP_EUNSUPPORTED = 2, SPHIP_ELAUNCH = 3, SPHIP_EWORKSPACE = 4 };
@@ -294,13 +294,20 @@ int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, 
  * read back by an optimizer pass. Same arithmetic as the two separate calls, bit for bit. Only
  * valid where the gradient has no other consumer (one rank, no accumulation). Workspace as for
  * sphip_segmented_weight_grad. sphip_segment_coeff_sums gives the bias gradient (sum of each
- * latent's coefficients, fused_encoder.py:80-84) that the unfused kernel returns as gbias. */
+ * latent's coefficients, fused_encoder.py:80-84) that the unfused kernel returns as gbias.
+ * coeff_sums (M) + bdec_partials (ceil(M / 32), D), both or neither: with them the kernel also
+ * leaves, per block of 32 latents, sum_j coeff_sums[j] * param_old[j, :] -- taken from the parameter
+ * pieces the update reads anyway; the column sums of bdec_partials are gb^T W_enc, the
+ * encoder-side term of b_dec's gradient (sparse_coder.py:192: sae_in = x - b_dec, through
+ * fused_encoder.py:56-65), which otherwise costs a pass of its own over the matrix (sphip_vec_mat)
+ * that must run before this call. */
 int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin,
                                         const void* coeff, int coeff_dtype, const void* rows,
                                         int rows_dtype, const float* row_shift, int64_t N, int64_t k,
                                         int64_t M, int64_t D, float* param, float lr,
-                                        void* bf16_shadow, void* workspace, size_t workspace_bytes,
-                                        void* stream);
+                                        void* bf16_shadow, const float* coeff_sums,
+                                        float* bdec_partials, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                              int coeff_dtype, int64_t M, float* out, void* stream);
 /* The same fusion for the reference's default optimizer "signum" (schedule-free SignSGD,
@@ -312,6 +319,7 @@ int sphip_segmented_weight_grad_schedulefree(const uint32_t* perm, const int32_t
                                              int rows_dtype, const float* row_shift, int64_t N,
                                              int64_t k, int64_t M, int64_t D, float* param, float* z,
                                              float lr, float beta, float c, void* bf16_shadow,
+                                             const float* coeff_sums, float* bdec_partials,
                                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* Sign exchange for data-parallel SignSGD (DDP gradient exchange, trainer.py:457-468, done as

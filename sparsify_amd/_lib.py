@@ -12,7 +12,7 @@ from pathlib import Path
 
 LIB_NAME = "libsparsify_hip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
 
@@ -70,8 +70,8 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_gather_rows_bf16": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
     "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P, _L, _L, _P]),
-    "sphip_segmented_weight_grad_signsgd": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _F, _P, _P, _Z, _P]),
-    "sphip_segmented_weight_grad_schedulefree": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _P, _F, _F, _F, _P, _P, _Z, _P]),
+    "sphip_segmented_weight_grad_signsgd": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _F, _P, _P, _P, _P, _Z, _P]),
+    "sphip_segmented_weight_grad_schedulefree": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _P, _F, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "sphip_segment_coeff_sums": (_I, [_P, _P, _P, _I, _L, _P, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),

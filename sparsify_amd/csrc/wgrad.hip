@@ -163,6 +163,12 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 // SignSGD to it (sign_sgd.py:23: p -= lr * sign(g)) and refreshes the bf16 shadow, so the
 // (M, D) gradient is neither written nor read back by an optimizer pass
 // (sphip_segmented_weight_grad_signsgd).
+// FUSE with bpart: the kernel also leaves, per workgroup, sum_j gb_in[j] * W_old[j, slice] over its 32
+// latents (gb_in = the latents' coefficient sums, sphip_segment_coeff_sums): the column sums of
+// these (M / 32, D) partials are gb^T W_enc, b_dec's encoder-side gradient (sparse_coder.py:192
+// through fused_encoder.py:56-65), taken from the parameter pieces the update reads anyway instead
+// of a pass of its own over the matrix. Order of the sum: the 8 latents of a wave by a butterfly
+// over its lane groups, then the four waves in order -- fixed by the segment lengths, not by timing.
 // DOT (fp32 rows): W is the table the rows were decoded with; the kernel also leaves, per slice,
 // the partial dot product <rows[n, slice], W[j, slice]> of every entry in slab[slice][position]
 // (8-lane butterfly per entry, lanes 0..3 of a group store the four entries of a batch as 16
@@ -179,7 +185,9 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                                                                const int* __restrict__ skew = nullptr, int skew_T = 0,
                                                                const float* __restrict__ Wdot = nullptr,
                                                                float* __restrict__ slab = nullptr, int64_t E = 0,
-                                                               SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
+                                                               SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f},
+                                                               const float* __restrict__ gb_in = nullptr,
+                                                               float* __restrict__ bpart = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // a workgroup holds 32 latents for as long as its longest segment lasts: with `skew` set,
@@ -199,7 +207,10 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // segment order: the sums do not change, only where they are computed.
     __shared__ int sh_sb[33];
     __shared__ int sh_ord[32];
+    __shared__ float sh_wp[FUSE ? 4 : 1][FUSE ? SLICE_COLS : 1];     // per-wave partials of gb^T W (bpart)
+    __shared__ int sh_cnt;                                           // waves that have left theirs
     if (threadIdx.x < 33) sh_sb[threadIdx.x] = seg_begin[min((int)lblock * 32 + (int)threadIdx.x, M)];
+    if (FUSE && threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
 #ifndef SPHIP_SLICED_SORT
 #define SPHIP_SLICED_SORT 1
@@ -241,6 +252,19 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     // FUSE: the parameter piece is requested now and used after the segment loop
     float wold[FUSE ? C : 1];
     float zold[FUSE ? C : 1];               // schedule-free form (sf.z != nullptr): the base iterate
+    // bpart: the pieces of latents left to the wide kernel (not `mine`) are read too -- that kernel
+    // updates them in a later launch on the same stream, so this one still sees the old values
+    const bool inrange = (j < M) && (col < D);
+    float gbj = 0.f;
+    if (FUSE && bpart != nullptr && inrange) gbj = gb_in[j];
+    if (FUSE && !live && bpart != nullptr && inrange) {
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gW + (int64_t)j * D + col + c));
+            wold[c] = t[0], wold[c + 1] = t[1], wold[c + 2] = t[2], wold[c + 3] = t[3];
+        }
+    }
     if (FUSE && live) {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
@@ -422,6 +446,36 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
         }
     }
     if (gbias != nullptr && slice == 0 && sub == 0 && j < M && mine) gbias[j] = bsum;
+    if constexpr (FUSE) {
+        if (bpart != nullptr) {                                   // kernel argument: uniform
+            float cb[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float t = inrange ? gbj * wold[c] : 0.f;
+                t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, true));  // lane ^ 8
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                cb[c] = t;
+            }
+            const int wv = threadIdx.x >> 6;
+            if (grp == 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) sh_wp[wv][sub * C + c] = cb[c];
+            }
+            // no workgroup barrier (the waves end at different times by design): every wave leaves
+            // its partial and counts itself; the one that counts last adds the four up
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            int prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&sh_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (prev == 3 && lane < SLICE_COLS) {
+                const float t = ((sh_wp[0][lane] + sh_wp[1][lane]) + sh_wp[2][lane]) + sh_wp[3][lane];
+                const int oc = (int)slice * SLICE_COLS + lane;
+                if (oc < D) bpart[(int64_t)lblock * D + oc] = t;
+            }
+        }
+    }
 }
 
 // gbias[j] = sum of the coefficients of latent j's segment, in segment order (the same chain as
@@ -668,7 +722,8 @@ template <typename RT, bool FUSE = false, bool DOT = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
                           float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr,
-                          const float* Wdot = nullptr, float* slab = nullptr, SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
+                          const float* Wdot = nullptr, float* slab = nullptr, SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f},
+                          const float* gb_in = nullptr, float* bpart = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -684,7 +739,7 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     if (nblocks >= (1ll << 31)) return false;
     hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                        (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf);
+                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
     return true;
 }
 
@@ -884,9 +939,12 @@ extern "C" int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg
 static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype,
                                   const void* rows, int rows_dtype, const float* row_shift, int64_t N, int64_t k,
                                   int64_t M, int64_t D, float* param, float lr, void* bf16_shadow, void* workspace,
-                                  size_t workspace_bytes, void* stream, sphip::SfArgs sf) {
+                                  size_t workspace_bytes, void* stream, sphip::SfArgs sf, const float* coeff_sums,
+                                  float* bdec_partials) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad_signsgd: bad dtype");
+    SPHIP_REQUIRE((coeff_sums == nullptr) == (bdec_partials == nullptr), SPHIP_EINVAL,
+                  "segmented_weight_grad_signsgd: coeff_sums and bdec_partials go together");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && param, SPHIP_EINVAL, "segmented_weight_grad_signsgd: null pointer");
     SPHIP_REQUIRE(N > 0 && k > 0 && M > 0 && D > 0, SPHIP_EINVAL, "segmented_weight_grad_signsgd: empty shape");
     SPHIP_REQUIRE(N * k < (1ll << 31) && M < (1ll << 31) - 4 && D < (1ll << 30), SPHIP_EUNSUPPORTED,
@@ -916,8 +974,8 @@ static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin
         hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
     }
     const bool done = rows_dtype == SPHIP_F32
-                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf)
-                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf);
+                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials)
+                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials);
     SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
     if (skew != nullptr) {
         const FastDiv kd = make_fastdiv((unsigned)k);
@@ -934,24 +992,28 @@ static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin
 extern "C" int sphip_segmented_weight_grad_signsgd(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                                    int coeff_dtype, const void* rows, int rows_dtype,
                                                    const float* row_shift, int64_t N, int64_t k, int64_t M, int64_t D,
-                                                   float* param, float lr, void* bf16_shadow, void* workspace,
-                                                   size_t workspace_bytes, void* stream) {
+                                                   float* param, float lr, void* bf16_shadow, const float* coeff_sums,
+                                                   float* bdec_partials, void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
     return fused_weight_grad_step(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, row_shift, N, k, M, D, param, lr,
-                                  bf16_shadow, workspace, workspace_bytes, stream, sphip::SfArgs{nullptr, 0.f, 0.f, 0.f});
+                                  bf16_shadow, workspace, workspace_bytes, stream, sphip::SfArgs{nullptr, 0.f, 0.f, 0.f},
+                                  coeff_sums, bdec_partials);
 }
 
 extern "C" int sphip_segmented_weight_grad_schedulefree(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                                         int coeff_dtype, const void* rows, int rows_dtype,
                                                         const float* row_shift, int64_t N, int64_t k, int64_t M,
                                                         int64_t D, float* param, float* z, float lr, float beta, float c,
-                                                        void* bf16_shadow, void* workspace, size_t workspace_bytes,
+                                                        void* bf16_shadow, const float* coeff_sums,
+                                                        float* bdec_partials, void* workspace, size_t workspace_bytes,
                                                         void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(z != nullptr && ((uintptr_t)z & 15) == 0, SPHIP_EINVAL,
                   "segmented_weight_grad_schedulefree: z must be a 16-byte aligned buffer");
     SPHIP_REQUIRE(beta > 0.f && beta <= 1.f, SPHIP_EINVAL, "segmented_weight_grad_schedulefree: bad beta");
     return fused_weight_grad_step(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, row_shift, N, k, M, D, param, lr,
-                                  bf16_shadow, workspace, workspace_bytes, stream, SfArgs{z, 1.f - 1.f / beta, c, 1.f - beta});
+                                  bf16_shadow, workspace, workspace_bytes, stream, SfArgs{z, 1.f - 1.f / beta, c, 1.f - beta},
+                                  coeff_sums, bdec_partials);
 }
 
 // table (M, D) fp32 row-major -> [D/32][M][32 floats]: one contiguous M x 128 B block per column

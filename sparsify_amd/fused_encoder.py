@@ -338,8 +338,8 @@ class FusedEncoder(torch.autograd.Function):
             seg = ops.cached_segments(indices, M)
             gb_full = ops.segment_coeff_sums(seg, gv)
             grad_bias = gb_full if bias is not None else None
-            if need_bdec and not need_x:
-                grad_bdec = ops.vec_mat(gb_full, weight.detach(), -1.0)    # reads W before its update
+            # b_dec's encoder-side gradient -gb^T W (W before its update) rides in the fused kernel
+            fold_bdec = need_bdec and not need_x
         elif need_w or need_b or need_bdec:
             seg = ops.cached_segments(indices, M)
             grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True, row_shift=shift)
@@ -352,18 +352,22 @@ class FusedEncoder(torch.autograd.Function):
             grad_input = gx.reshape(ctx.in_shape)
             if need_bdec:
                 grad_bdec = ops.colsum(gx, -1.0)
-        elif need_bdec and grad_bdec is None:
+        elif need_bdec and not fuse:
             # sum_n grad_x[n,:] = gb^T W : one pass over W instead of an (N,k)-row gather
             grad_bdec = ops.vec_mat(gb_full, weight.detach(), -1.0)
         if fuse:
             # every reader of the old weight in this backward has been enqueued: update in place
             shadow = peek_bf16_shadow(weight)
             how = lr_of()                    # lr, or {"lr", "z", "beta", "c"} for the schedule-free wrapper
+            sums = gb_full if fold_bdec else None
             if isinstance(how, dict):
-                ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how["lr"], shadow, row_shift=shift,
-                                                   schedule_free=(how["z"], how["beta"], how["c"]))
+                res = ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how["lr"], shadow, row_shift=shift,
+                                                         schedule_free=(how["z"], how["beta"], how["c"]), coeff_sums=sums)
             else:
-                ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how, shadow, row_shift=shift)
+                res = ops.segmented_weight_grad_signsgd_(seg, gv, rows, weight.data, how, shadow, row_shift=shift,
+                                                         coeff_sums=sums)
+            if fold_bdec:
+                grad_bdec = ops.colsum(res[1], -1.0)
             torch.autograd.graph.increment_version(weight)
             if shadow is not None:
                 register_bf16_shadow(weight, shadow)

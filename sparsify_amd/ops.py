@@ -478,11 +478,13 @@ def segment_coeff_sums(seg: LatentSegments, coeff: Tensor) -> Tensor:
 
 def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Tensor, param: Tensor, lr: float,
                                    bf16_shadow: Tensor | None = None, row_shift: Tensor | None = None,
-                                   schedule_free: tuple | None = None) -> Tensor:
+                                   schedule_free: tuple | None = None, coeff_sums: Tensor | None = None):
     """param -= lr * sign(weight gradient) without materialising the gradient (fused_encoder.py:67-77
     + sign_sgd.py:23); the same arithmetic as segmented_weight_grad followed by signsgd_step_.
     schedule_free = (z, beta, c): the schedule-free step of (param = y, z) instead
-    (schedulefree_signsgd_step_)."""
+    (schedulefree_signsgd_step_). coeff_sums (segment_coeff_sums(seg, coeff)): also returns the
+    (ceil(M / 32), D) partial sums of coeff_sums^T param_old (their column sum is vec_mat(coeff_sums,
+    param_old)), read off the parameter pieces the update touches anyway; returns (param, partials)."""
     _req(coeff, "coeff", ndim=2)
     _req(rows, "rows", ndim=2)
     _req(param, "param", torch.float32, 2)
@@ -498,13 +500,20 @@ def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Ten
         _req(bf16_shadow, "bf16_shadow", torch.bfloat16, 2)
         if bf16_shadow.shape != param.shape:
             raise ValueError("segmented_weight_grad_signsgd: shadow shape mismatch")
+    partials = None
+    if coeff_sums is not None:
+        _req(coeff_sums, "coeff_sums", torch.float32, 1)
+        if coeff_sums.shape[0] != M:
+            raise ValueError("segmented_weight_grad_signsgd: coeff_sums shape mismatch")
+        partials = torch.empty(-(-M // 32), D, dtype=torch.float32, device=param.device)
     lib = _lib.load()
     ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
     _ev = timer.start("sphip_segmented_weight_grad_signsgd", rows)
     if schedule_free is None:
         check(lib.sphip_segmented_weight_grad_signsgd(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
                                                       _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(row_shift), N, k, M, D,
-                                                      param.data_ptr(), float(lr), _ptr(bf16_shadow), ws.data_ptr(),
+                                                      param.data_ptr(), float(lr), _ptr(bf16_shadow), _ptr(coeff_sums),
+                                                      _ptr(partials), ws.data_ptr(),
                                                       ws.numel(), _stream(rows)), "sphip_segmented_weight_grad_signsgd")
     else:
         z, beta, c = schedule_free
@@ -514,9 +523,10 @@ def segmented_weight_grad_signsgd_(seg: LatentSegments, coeff: Tensor, rows: Ten
         check(lib.sphip_segmented_weight_grad_schedulefree(
             seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(), _dt(coeff), rows.data_ptr(), _dt(rows),
             _ptr(row_shift), N, k, M, D, param.data_ptr(), z.data_ptr(), float(lr), float(beta), float(c),
-            _ptr(bf16_shadow), ws.data_ptr(), ws.numel(), _stream(rows)), "sphip_segmented_weight_grad_schedulefree")
+            _ptr(bf16_shadow), _ptr(coeff_sums), _ptr(partials), ws.data_ptr(), ws.numel(), _stream(rows)),
+            "sphip_segmented_weight_grad_schedulefree")
     timer.stop(_ev, rows)
-    return param
+    return param if coeff_sums is None else (param, partials)
 
 
 # ------------------------------------------------------------------ loss pieces

@@ -680,6 +680,17 @@ def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, ske
     ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused, lr, sh_fused, row_shift=shift)
     assert torch.equal(sep, fused) and torch.equal(sh_sep.view(torch.int16), sh_fused.view(torch.int16))
     assert torch.equal(ops.segment_coeff_sums(seg, coeff), gb)
+    # ... and, given the coefficient sums, it leaves per block of 32 latents the partial sums of
+    # gb^T W_old (b_dec's encoder-side gradient, otherwise a vec_mat pass before the update):
+    # same update bit for bit, the partials against fp64 and identical on a second run
+    fused2, fused3 = p0.clone(), p0.clone()
+    _, part = ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused2, lr, sh_fused, row_shift=shift, coeff_sums=gb)
+    _, part3 = ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused3, lr, None, row_shift=shift, coeff_sums=gb)
+    assert torch.equal(fused2, sep) and torch.equal(sh_sep.view(torch.int16), sh_fused.view(torch.int16))
+    assert part.shape == (M // 32, D) and torch.equal(part, part3)
+    want = (gb.double()[:, None] * p0.double()).view(M // 32, 32, D).sum(1)
+    torch.testing.assert_close(part.double(), want, rtol=1e-5, atol=1e-4 * float(want.abs().max()))
+    torch.testing.assert_close(ops.colsum(part, -1.0), ops.vec_mat(gb, p0, -1.0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("skewed", [False, True])
