@@ -33,6 +33,8 @@ GiB = 2**30 / 1e6
 t("signsgd + shadow", lambda: ops.signsgd_step_(W, G, 1e-9, sh), 7 * 2 * GiB)
 t("signsgd", lambda: ops.signsgd_step_(W, G, 1e-9), 6 * 2 * GiB)
 t("decoder project+sign+renorm", lambda: ops.decoder_project_signsgd_(W, G, 1e-9, True), 6 * 2 * GiB)
+smb = torch.empty(M * D, device=dev)
+t("decoder project+sign+renorm+slice-major", lambda: ops.decoder_project_signsgd_(W, G, 1e-9, True, smb), 8 * 2 * GiB)
 t("unit_norm", lambda: ops.unit_norm_rows_(W), 4 * 2 * GiB)
 t("apply_signs + shadow", lambda: ops.apply_signs_(W, sg, 1e-9, sh), (4 + 1 + 4 + 2) * 0.5 * GiB)
 t("decoder apply_signs + renorm", lambda: ops.decoder_apply_signs_(W, sg, 1e-9, True), (4 + 1 + 4) * 0.5 * GiB)

@@ -131,11 +131,34 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
     float* w = W + (int64_t)blockIdx.x * D;
     const float* g = G + (int64_t)blockIdx.x * D;
     float4 b[R], a[R];
+    // every stream crosses the kernel once (two 2 GiB matrices in, one or two out): non-temporal
+    // accesses, bits 1 / 2 / 4 / 8 = W load, G load, W store, slice-major store. A/B on one box
+    // (make EXTRA=-DSPHIP_DEC_NT=n): 0 -> 1.649 ms, 2 -> 1.667, 6 -> 1.668, 14 -> 1.615, 15 -> 1.576 ms
+    // with the slice-major copy; 1.176 -> 1.050 ms without it
+#ifndef SPHIP_DEC_NT
+#define SPHIP_DEC_NT 15
+#endif
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ld = [](const float* p, bool nt) {
+        if (nt) {
+            const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+            return make_float4(t[0], t[1], t[2], t[3]);
+        }
+        return *reinterpret_cast<const float4*>(p);
+    };
+    auto st = [](float* p, float4 v, bool nt) {
+        if (nt) {
+            const f4 t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+        } else {
+            *reinterpret_cast<float4*>(p) = v;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int c = (threadIdx.x + 256 * i) * 4;
-        b[i] = c < D ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (OP != 0) a[i] = c < D ? *reinterpret_cast<const float4*>(g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[i] = c < D ? ld(w + c, (SPHIP_DEC_NT & 1) != 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (OP != 0) a[i] = c < D ? ld(g + c, (SPHIP_DEC_NT & 2) != 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (OP != 0) {
         float acc = 0.f;
@@ -176,9 +199,9 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
         const int c4 = threadIdx.x + 256 * i;               // 16-byte chunk of the row
         const int c = c4 * 4;
         if (c < D) {
-            *reinterpret_cast<float4*>(w + c) = b[i];
+            st(w + c, b[i], (SPHIP_DEC_NT & 4) != 0);
             // slice c4 / 8, piece of row blockIdx.x, chunk c4 % 8: eight threads write one 128-byte line
-            if (SM) *reinterpret_cast<float4*>(sm + (((int64_t)(c4 >> 3) * M + blockIdx.x) * 8 + (c4 & 7)) * 4) = b[i];
+            if (SM) st(sm + (((int64_t)(c4 >> 3) * M + blockIdx.x) * 8 + (c4 & 7)) * 4, b[i], (SPHIP_DEC_NT & 8) != 0);
         }
     }
 }

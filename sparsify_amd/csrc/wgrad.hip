@@ -18,6 +18,25 @@
 
 namespace sphip {
 
+// timing experiments on the fused update (make EXTRA=-DSPHIP_FUSE_X=n): bit 1 no parameter store, 2 no shadow store
+#ifndef SPHIP_FUSE_X
+#define SPHIP_FUSE_X 0
+#endif
+// The fused (optimizer-in-kernel) form of the L2-sliced kernel holds the parameter piece across
+// the segment loop and needs ~82 registers with four pieces in flight: five waves per SIMD. It is
+// compiled for SPHIP_FUSE_WAVES waves (register budget 512 / waves) with SPHIP_FUSE_U pieces in
+// flight per lane group; the other forms keep the compiler's own allocation (56-66 registers;
+// forcing the dot form from 66 to 60 registers for an eighth wave measured 4.33 against 4.27 ms).
+// A/B on one box (make EXTRA="-DSPHIP_FUSE_WAVES=w -DSPHIP_FUSE_U=u"): 5 waves x 4 pieces 2.65 ms,
+// 6 x 4 2.42, 7 x 3 2.38, 8 x 2 2.37 (7 x 4 and 8 x 4 spill: 2.46 / 2.81). The schedule-free form
+// (the z piece on top) is compiled for one wave less.
+#ifndef SPHIP_FUSE_WAVES
+#define SPHIP_FUSE_WAVES 7
+#endif
+#ifndef SPHIP_FUSE_U
+#define SPHIP_FUSE_U 3
+#endif
+
 // Segment-ordered entry list: packed[p] = {entry id e = perm[p], fp32 bits of coeff[e]}.
 // Turns the per-entry dependent gather (perm -> coeff) of the reduction kernels into one
 // sequential 8-byte stream; built once per call (N*k entries, a few tens of microseconds).
@@ -122,19 +141,21 @@ __global__ __launch_bounds__(256) void seg_wgrad_kernel(const uint2* __restrict_
 template <typename T> struct Piece;
 template <> struct Piece<float> {
     static constexpr int COLS = 4;    // columns per lane (16 B)
-    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    typedef float4 Raw;
+    static __device__ __forceinline__ Raw load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ Raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float get(const Raw& r, int c) { return c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w; }
 };
+// bf16 pieces stay as loaded (4 registers instead of 8 floats; four of them are in flight per lane)
+// and are widened where they are consumed: one shift or mask per element
 template <> struct Piece<bf16_t> {
     static constexpr int COLS = 8;
-    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-        v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-        v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    typedef uint4 Raw;
+    static __device__ __forceinline__ Raw load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ Raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+    static __device__ __forceinline__ float get(const Raw& r, int c) {
+        const unsigned w = (c >> 1) == 0 ? r.x : (c >> 1) == 1 ? r.y : (c >> 1) == 2 ? r.z : r.w;
+        return __uint_as_float((c & 1) ? (w & 0xffff0000u) : (w << 16));
     }
 };
 
@@ -173,8 +194,8 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 // the partial dot product <rows[n, slice], W[j, slice]> of every entry in slab[slice][position]
 // (8-lane butterfly per entry, lanes 0..3 of a group store the four entries of a batch as 16
 // contiguous bytes); seg_dcoeff_bounded_kernel sums the slices in order.
-template <typename RT, bool FUSE = false, bool DOT = false>
-__global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
+template <typename RT, bool FUSE = false, bool DOT = false, bool SFREE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 1, FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     float bsum = 0.f;
     // FUSE: the parameter piece is requested now and used after the segment loop
     float wold[FUSE ? C : 1];
-    float zold[FUSE ? C : 1];               // schedule-free form (sf.z != nullptr): the base iterate
+    float zold[(FUSE && SFREE) ? C : 1];               // schedule-free form (sf.z != nullptr): the base iterate
     // bpart: the pieces of latents left to the wide kernel (not `mine`) are read too -- that kernel
     // updates them in a later launch on the same stream, so this one still sees the old values
     const bool inrange = (j < M) && (col < D);
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gW + (int64_t)j * D + col + c));
             wold[c] = t[0], wold[c + 1] = t[1], wold[c + 2] = t[2], wold[c + 3] = t[3];
-            if (sf.z != nullptr) {
+            if (SFREE) {
                 const f4 u = __builtin_nontemporal_load(reinterpret_cast<const f4*>(sf.z + (int64_t)j * D + col + c));
                 zold[c] = u[0], zold[c + 1] = u[1], zold[c + 2] = u[2], zold[c + 3] = u[3];
             }
@@ -294,13 +315,14 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
     }
     float* sl = DOT ? slab + (int64_t)slice * E : nullptr;
     // partial dots of the batch at positions p .. p + U - 1 (entries past `stop` are not stored)
-    auto dots = [&](const float (*v)[C], int p, int stop, int count) {
+    typedef typename Piece<RT>::Raw Raw;
+    auto dots = [&](const Raw* v, int p, int stop, int count) {
         float mine_d = 0.f;
 #pragma unroll
         for (int u = 0; u < count; ++u) {
             float d = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) d = fmaf(v[u][c], wdot[c], d);
+            for (int c = 0; c < C; ++c) d = fmaf(Piece<RT>::get(v[u], c), wdot[c], d);
             // sum over the 8 lanes of the group with DPP moves (quad xor 1, quad xor 2, half-row
             // mirror) instead of three ds_bpermute round trips through the LDS pipe per entry; the
             // quad sums are the same bits in all four lanes (commutative adds), so lane 7 - i
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
 #ifndef SPHIP_SLICED_U
 #define SPHIP_SLICED_U 4
 #endif
-    constexpr int U = SPHIP_SLICED_U;
+    constexpr int U = FUSE ? SPHIP_FUSE_U : SPHIP_SLICED_U;
     auto run = [&](auto entry) {
         const int last = max(end - 1, 0);
         uint2 nxt[U];
@@ -348,11 +370,11 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
         int p = beg;
         for (; p + U <= end; p += U) {
             uint2 pk[U];
-            float v[U][C];
+            Raw v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
-            for (int u = 0; u < U; ++u) Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C), v[u]);
+            for (int u = 0; u < U; ++u) v[u] = Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C));
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
             if (DOT) dots(v, p, end, U);
@@ -360,24 +382,16 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
             for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
                 const float cf = __uint_as_float(pk[u].y);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, Piece<RT>::get(v[u], c), acc[c]);
                 bsum += cf;
             }
         }
         if (p < end) {
-            float v[U][C];
+            Raw v[U];
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
-                if (p + u < end) Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C), v[u]);
-            }
-            if (DOT) {
-#pragma unroll
-                for (int u = 0; u < U - 1; ++u) {
-                    if (!(p + u < end)) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) v[u][c] = 0.f;
-                    }
-                }
+                v[u] = Piece<RT>::zero();
+                if (p + u < end) v[u] = Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C));
             }
             if (DOT) dots(v, p, end, U - 1);
 #pragma unroll
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
                 if (p + u < end) {
                     const float cf = __uint_as_float(nxt[u].y);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, v[u][c], acc[c]);
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, Piece<RT>::get(v[u], c), acc[c]);
                     bsum += cf;
                 }
             }
@@ -395,19 +409,68 @@ __global__ __launch_bounds__(256) void seg_wgrad_sliced_kernel(const uint2* __re
         if (staged) run([&](int pos) { return sh_pk[pos - rb]; });
         else run([&](int pos) { return packed[pos]; });
     }
-    if (live) {
-        if (row_shift != nullptr) {
+    if (live && row_shift != nullptr) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(-bsum, row_shift[col + c], acc[c]);
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(-bsum, row_shift[col + c], acc[c]);
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if constexpr (FUSE && C == 8) {
+        // bf16 rows: a lane owns 8 consecutive columns, i.e. 32 bytes of the fp32 parameter row, so
+        // two 16-byte stores per lane would each fill every other 16-byte chunk of two lines
+        // (measured: the 2 GiB parameter store cost 0.40 ms of the kernel's 2.57, the 1 GiB shadow
+        // store, whole lines, 0.14). The updated values change lanes inside the group first
+        // (lane d takes columns 4d .. 4d+3 and 32+4d .. 32+4d+3) and leave as whole 128-byte lines.
+        // Every lane of the wave takes part in the exchange; lanes that are not live store nothing.
+        float wn[8], zn[SFREE ? 8 : 1];
+        unsigned short shv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = acc[e];
+            float y1 = wold[e], z1 = SFREE ? zold[e] : 0.f;
+            if (SFREE) sf_update(y1, z1, (float)((g > 0.f) - (g < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+            else y1 -= lr * (float)((g > 0.f) - (g < 0.f));
+            wn[e] = y1;
+            if (SFREE) zn[e] = z1;
+            shv[e] = f32_to_bf16(y1);
         }
+        if (live && shadow != nullptr && !(SPHIP_FUSE_X & 2)) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 t = {(unsigned)shv[0] | ((unsigned)shv[1] << 16), (unsigned)shv[2] | ((unsigned)shv[3] << 16),
+                          (unsigned)shv[4] | ((unsigned)shv[5] << 16), (unsigned)shv[6] | ((unsigned)shv[7] << 16)};
+            __builtin_nontemporal_store(t, reinterpret_cast<u4*>(shadow + (int64_t)j * D + col));
+        }
+        const int srcA = (lane & ~7) + (sub >> 1), srcB = srcA + 4;
+        const bool odd = (sub & 1) != 0;
+        auto to_lines = [&](const float (&v)[8], f4& A, f4& B) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float alo = __shfl(v[q], srcA, 64), ahi = __shfl(v[4 + q], srcA, 64);
+                const float blo = __shfl(v[q], srcB, 64), bhi = __shfl(v[4 + q], srcB, 64);
+                A[q] = odd ? ahi : alo;
+                B[q] = odd ? bhi : blo;
+            }
+        };
+        const int colA = (int)slice * SLICE_COLS + sub * 4, colB = colA + 32;
+        const bool rowlive = (j < M) && mine;                  // uniform over the lane group
+        f4 A, B;
+        to_lines(wn, A, B);
+        if (!(SPHIP_FUSE_X & 1)) {
+            if (rowlive && colA < D) __builtin_nontemporal_store(A, reinterpret_cast<f4*>(gW + (int64_t)j * D + colA));
+            if (rowlive && colB < D) __builtin_nontemporal_store(B, reinterpret_cast<f4*>(gW + (int64_t)j * D + colB));
+        }
+        if constexpr (SFREE) {
+            to_lines(zn, A, B);
+            if (rowlive && colA < D) __builtin_nontemporal_store(A, reinterpret_cast<f4*>(sf.z + (int64_t)j * D + colA));
+            if (rowlive && colB < D) __builtin_nontemporal_store(B, reinterpret_cast<f4*>(sf.z + (int64_t)j * D + colB));
+        }
+    } else if (live) {
         float* o = gW + (int64_t)j * D + col;
-        typedef float f4 __attribute__((ext_vector_type(4)));
         if (FUSE) {
             unsigned short sh[C];
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
                 f4 w = {wold[c], wold[c + 1], wold[c + 2], wold[c + 3]};
-                if (sf.z != nullptr) {
+                if constexpr (SFREE) {
                     f4 z = {zold[c], zold[c + 1], zold[c + 2], zold[c + 3]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -737,9 +800,14 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
-                       (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                       shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+    if (FUSE && sf.z != nullptr)
+        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
+                           (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+    else
+        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, false>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
+                           (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
     return true;
 }
 
