@@ -85,6 +85,36 @@ def test_decode_is_linear_and_adjoint_to_the_weight_gradient(state):
     assert bool(((lat.diff() > 0) | (perm.diff() > 0)).all())
 
 
+def test_fused_encoder_update_at_full_size(state):
+    """The fused encoder-gradient kernel (sorted lane-group assignment, 7 waves, whole-line
+    parameter stores, b_dec partial sums) at the headline shape: bit for bit gradient + separate
+    SignSGD step and bf16 shadow; the column sums of its per-block partials equal gb^T W_old
+    (sphip_vec_mat) to fp32 summation order; a second run gives identical bits."""
+    from sparsify_amd import ops
+    g = state["gen"]
+    idx, rows = state["idx"], state["x"]
+    gv = torch.randn(N, K, device="cuda", generator=g).to(torch.bfloat16)
+    shift = torch.randn(D, device="cuda", generator=g)
+    lr = 1e-3
+    seg = ops.build_latent_segments(idx, M)
+    gW, gb, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True, row_shift=shift)
+    assert torch.equal(ops.segment_coeff_sums(seg, gv), gb)
+    want_bdec = ops.vec_mat(gb, state["W"], -1.0)
+    sep = state["W"].clone()
+    sh_sep = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    ops.signsgd_step_(sep, gW, lr, sh_sep)
+    del gW
+    fused = state["W"].clone()
+    sh_fused = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    _, part = ops.segmented_weight_grad_signsgd_(seg, gv, rows, fused, lr, sh_fused, row_shift=shift, coeff_sums=gb)
+    assert torch.equal(fused, sep) and torch.equal(sh_fused.view(torch.int16), sh_sep.view(torch.int16))
+    got_bdec = ops.colsum(part, -1.0)
+    torch.testing.assert_close(got_bdec, want_bdec, rtol=1e-4, atol=1e-5 * float(want_bdec.abs().max()) + 1e-6)
+    fused.copy_(state["W"])
+    _, part2 = ops.segmented_weight_grad_signsgd_(seg, gv, rows, fused, lr, sh_fused, row_shift=shift, coeff_sums=gb)
+    assert torch.equal(part, part2) and torch.equal(fused, sep)
+
+
 def test_decoder_step_and_unit_norm_are_idempotent_where_they_should_be(state):
     from sparsify_amd import ops
     W = state["W"].clone()
