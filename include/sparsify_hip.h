@@ -387,6 +387,10 @@ int sphip_dead_mask(const int64_t* counts, int64_t M, int64_t threshold, uint8_t
  *   sphip_gemm_bf16_f32acc:      out (N, ld_out) fp32 (+)= x (N,K) W (M,K)^T, bf16 operands, fp32
  *                                accumulate; accumulate != 0 adds to what out holds. K % 64 == 0
  *   sphip_scatter_rows:          dst (M, D) = 0; dst[row_list[r], :] = src[r, :] for r < R
+ *   sphip_scatter_add_rows:      dst[row_list[r], :] += src[r, :] for r < R (distinct rows): the dead
+ *                                rows' gradient added into the dense W_dec gradient the main decode's
+ *                                backward has produced, instead of a dense (M, D) temporary and an
+ *                                (M, D) addition by the autograd engine
  *   sphip_broadcast_rows:        out[n, :] = bias (the `+ b_dec` the products are added to)
  *   sphip_gather_rows_bf16:      dst (rows_out, D) bf16 = src[row_list[r], :] for r < R, zero rows
  *                                after: the dead latents' encoder rows / bias, from which
@@ -405,6 +409,8 @@ int sphip_split_bf16_transposed(const float* src, const int64_t* row_list, int64
 int sphip_gemm_bf16_f32acc(const void* x, const void* W, float* out, int64_t N, int64_t K,
                            int64_t M, int64_t ld_out, int accumulate, void* stream);
 int sphip_scatter_rows(const float* src, const int64_t* row_list, int64_t R, int64_t D, int64_t M,
+                       float* dst, void* stream);
+int sphip_scatter_add_rows(const float* src, const int64_t* row_list, int64_t R, int64_t D, int64_t M,
                        float* dst, void* stream);
 int sphip_broadcast_rows(const float* bias, int64_t N, int64_t D, float* out, void* stream);
 int sphip_gather_rows_bf16(const void* src, const int64_t* row_list, int64_t R, int64_t rows_out,

@@ -66,6 +66,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_split_bf16_transposed": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
     "sphip_gemm_bf16_f32acc": (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _P]),
     "sphip_scatter_rows": (_I, [_P, _P, _L, _L, _L, _P, _P]),
+    "sphip_scatter_add_rows": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_broadcast_rows": (_I, [_P, _L, _L, _P, _P]),
     "sphip_gather_rows_bf16": (_I, [_P, _P, _L, _L, _L, _P, _P]),
     "sphip_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),

@@ -119,6 +119,19 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     reinterpret_cast<float4*>(dst)[list[r] * D4 + c] = reinterpret_cast<const float4*>(src)[i];
 }
 
+// dst[list[r], :] += src[r, :] (the rows of `list` are distinct: plain read-modify-write)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src,
+                                                               const int64_t* __restrict__ list, int64_t R, int D4,
+                                                               float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * D4) return;
+    const int64_t r = i / D4;
+    const int c = (int)(i - r * D4);
+    float4* d = reinterpret_cast<float4*>(dst) + list[r] * D4 + c;
+    const float4 a = *d, b = reinterpret_cast<const float4*>(src)[i];
+    *d = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 // dst row r = src row list[r] for r < R, zero for R <= r < rows_out; rows of `units` 2-byte
 // elements (the bf16 shadow of the encoder rows / bias of the dead latents)
 __global__ __launch_bounds__(256) void gather_rows_u16_kernel(const bf16_t* __restrict__ src,
@@ -226,6 +239,21 @@ extern "C" int sphip_scatter_rows(const float* src, const int64_t* row_list, int
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, src, row_list, R,
                        (int)(D / 4), dst);
     SPHIP_CHECK_LAUNCH("scatter_rows");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_scatter_add_rows(const float* src, const int64_t* row_list, int64_t R, int64_t D, int64_t M,
+                                      float* dst, void* stream) {
+    SPHIP_REQUIRE(src && row_list && dst, SPHIP_EINVAL, "scatter_add_rows: null pointer");
+    SPHIP_REQUIRE(R > 0 && D > 0 && M >= R && D % 4 == 0, SPHIP_EINVAL, "scatter_add_rows: bad sizes R=%lld D=%lld M=%lld",
+                  (long long)R, (long long)D, (long long)M);
+    SPHIP_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, SPHIP_EINVAL,
+                  "scatter_add_rows: src and dst must be 16-byte aligned");
+    const int64_t total = R * (D / 4);
+    SPHIP_REQUIRE(cdiv(total, 256) < (1ll << 31), SPHIP_EUNSUPPORTED, "scatter_add_rows: too many elements");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       row_list, R, (int)(D / 4), dst);
+    SPHIP_CHECK_LAUNCH("scatter_add_rows");
     return SPHIP_OK;
 }
 

@@ -10,6 +10,7 @@ from the reference's fp32 embedding_bag)."""
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 from torch import Tensor
@@ -35,6 +36,39 @@ def eligible(pre_acts: Tensor, k_aux: int, W_dec: Tensor, num_dead: int) -> bool
     return num_dead <= DENSE_RATIO * k_aux and pre_acts.shape[0] * k_aux >= MIN_ENTRIES
 
 
+# Gradient rows of the dead latents waiting for the dense W_dec gradient of the same backward pass.
+# DeadLatentDecode.backward runs before the main decode's backward (it was recorded later); instead
+# of returning an (M, D) tensor that is zero outside the dead rows -- a 2 GiB fill plus an (M, D)
+# addition by the autograd engine at the headline shape, 1.6 ms -- it parks its (n_dead, D) rows
+# here, keyed by the parameter's storage address (validated through a weak reference), and utils.SparseDecode.backward adds them into the dense gradient
+# it returns (claim_pending_rows). A callback queued on the autograd engine settles whatever is
+# still parked when the backward pass ends (no main decode in the graph): it then goes into
+# W_dec.grad directly.
+_pending_rows: dict[int, list] = {}
+
+
+def claim_pending_rows(weight: Tensor, gW: Tensor) -> None:
+    """Add the parked dead-latent gradient rows of `weight` into its dense gradient gW, in place."""
+    for ref, G, dead_list, num_dead in _pending_rows.pop(weight.data_ptr(), []):
+        w = ref()
+        if w is not None and w.data_ptr() == weight.data_ptr() and w.shape == gW.shape:
+            ops.scatter_add_rows_(gW, G, dead_list, num_dead)
+        elif w is not None:                                     # another tensor at a recycled address
+            _pending_rows.setdefault(w.data_ptr(), []).append((ref, G, dead_list, num_dead))
+
+
+def _settle_pending_rows() -> None:
+    for key in list(_pending_rows):
+        for ref, G, dead_list, num_dead in _pending_rows.pop(key, []):
+            w = ref()
+            if w is None:
+                continue
+            if w.grad is None:
+                w.grad = ops.scatter_rows(G, dead_list, num_dead, w.shape[0])
+            else:
+                ops.scatter_add_rows_(w.grad, G, dead_list, num_dead)
+
+
 class DeadLatentDecode(torch.autograd.Function):
     """decode(auxk_acts, auxk_indices) for indices that all lie on dead latents; gradients for
     W_dec and b_dec only (the gradient w.r.t. the activations would flow into pre_acts, which
@@ -54,6 +88,7 @@ class DeadLatentDecode(torch.autograd.Function):
         for p in range(3):
             ops.gemm_bf16_f32acc(A, w_parts[p], out, accumulate=True)
         ctx.save_for_backward(At, dead_list)
+        ctx.weight_ref = weakref.ref(W_dec) if isinstance(W_dec, torch.nn.Parameter) else None
         ctx.dims = (N, M, D, num_dead)
         ctx.set_materialize_grads(False)
         return out
@@ -71,7 +106,12 @@ class DeadLatentDecode(torch.autograd.Function):
             G = torch.empty(At.shape[0], D, dtype=torch.float32, device=g.device)
             for p in range(3):
                 ops.gemm_bf16_f32acc(At, g_parts[p], G, accumulate=p > 0)
-            gW = ops.scatter_rows(G, dead_list, num_dead, M)
+            w = ctx.weight_ref() if ctx.weight_ref is not None else None
+            if w is not None and w.is_leaf:
+                _pending_rows.setdefault(w.data_ptr(), []).append((ctx.weight_ref, G, dead_list, num_dead))
+                torch.autograd.Variable._execution_engine.queue_callback(_settle_pending_rows)
+            else:
+                gW = ops.scatter_rows(G, dead_list, num_dead, M)
         if ctx.needs_input_grad[3]:
             gb = ops.colsum(g, 1.0)
         return None, None, gW, gb, None, None, None

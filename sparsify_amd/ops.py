@@ -873,6 +873,18 @@ def scatter_rows(src: Tensor, row_list: Tensor, R: int, M: int) -> Tensor:
     return dst
 
 
+def scatter_add_rows_(dst: Tensor, src: Tensor, row_list: Tensor, R: int) -> Tensor:
+    """dst[row_list[r]] += src[r] for r < R (distinct rows), in place."""
+    _req(dst, "dst", torch.float32, 2)
+    _req(src, "src", torch.float32, 2)
+    _req(row_list, "row_list", torch.int64, 1)
+    if src.shape[0] < R or row_list.shape[0] < R or src.shape[1] != dst.shape[1]:
+        raise ValueError("scatter_add_rows: shape mismatch")
+    check(_lib.load().sphip_scatter_add_rows(src.data_ptr(), row_list.data_ptr(), R, dst.shape[1], dst.shape[0],
+                                            dst.data_ptr(), _stream(src)), "sphip_scatter_add_rows")
+    return dst
+
+
 def broadcast_rows(bias: Tensor, N: int) -> Tensor:
     _req(bias, "bias", torch.float32, 1)
     out = torch.empty(N, bias.shape[0], dtype=torch.float32, device=bias.device)

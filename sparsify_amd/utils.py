@@ -52,6 +52,9 @@ class SparseDecode(torch.autograd.Function):
                                                   want_dcoeff=need_a)
             if gA is not None and gA.dtype != psw.dtype:
                 gA = gA.to(psw.dtype)
+            if need_w:
+                from . import dead_decode
+                dead_decode.claim_pending_rows(weight, gW)     # AuxK rows of this backward pass (dead_decode.py)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gB = ops.colsum(g)
         return None, gW, gA, gB

@@ -159,6 +159,41 @@ def test_sparse_coder_bf16_auxk_dense_products_vs_reference(device, name, monkey
         ops.timer.reset()
 
 
+def test_auxk_dense_gradient_rows_without_a_main_decode_backward(device, monkeypatch):
+    """The dense AuxK path parks its (n_dead, D) gradient rows for the main decode's backward to add
+    into the dense W_dec gradient (dead_decode.claim_pending_rows). When that backward does not run
+    in the same pass (auxk_loss backpropagated on its own) the rows go into W_dec.grad when the pass
+    ends: fvu and auxk_loss backpropagated one after the other leave bit for bit the gradients of
+    one backward over their sum, and nothing stays parked."""
+    from sparsify_amd import dead_decode
+    monkeypatch.setenv("SPHIP_AUXK", "dense")
+    g = load_golden([n for n in golden_names("coder_") if "_bf16_" in n and "fewdead" in n][0])
+    name = [n for n in golden_names("coder_") if "_bf16_" in n and "fewdead" in n][0]
+    grads = []
+    for split in (False, True):
+        sae, mode = build_sae(g, name)
+        out = run_coder(sae, mode, g["x"].cuda(), g["y"].cuda() if "y" in g else None, g["dead_mask"].cuda())
+        if split:
+            out.fvu.backward(retain_graph=True)
+            (g["alpha"] * out.auxk_loss).backward()
+        else:
+            (out.fvu + g["alpha"] * out.auxk_loss).backward()
+        assert not dead_decode._pending_rows
+        grads.append(param_grads(sae, g))
+    for k in grads[0]:
+        if k == "b_dec":      # three contributions: the engine adds them in another order over two passes
+            torch.testing.assert_close(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-7)
+        else:
+            assert torch.equal(grads[0][k], grads[1][k]), k
+    # auxk_loss alone: W_dec.grad holds the dead rows' gradient only
+    sae, mode = build_sae(g, name)
+    out = run_coder(sae, mode, g["x"].cuda(), g["y"].cuda() if "y" in g else None, g["dead_mask"].cuda())
+    out.auxk_loss.backward()
+    assert not dead_decode._pending_rows
+    gW = sae.W_dec.grad.cpu()
+    assert gW[~g["dead_mask"]].abs().max() == 0 and gW[g["dead_mask"]].abs().max() > 0
+
+
 def check_bf16_golden(name):
     """bf16 autocast. (a) the chosen top-k sets equal the reference's except at near ties of
     the k-th boundary (north_star rule); (b) on rows with identical sets, values and
