@@ -693,6 +693,43 @@ def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, ske
     torch.testing.assert_close(ops.colsum(part, -1.0), ops.vec_mat(gb, p0, -1.0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("N,D,M,k", [(300, 200, 1000, 8), (257, 72, 95, 5), (1024, 328, 4100, 16)])
+@pytest.mark.parametrize("rdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("sfree", [False, True])
+def test_fused_weight_grad_step_ragged_shapes(device, N, D, M, k, rdtype, sfree):
+    """The fused weight-gradient + optimizer kernel on shapes that are not whole blocks of 32
+    latents nor whole 128-byte column slices (the lane exchange before the parameter store, the
+    partial last slice, the per-block partial sums of gb^T W): bit for bit gradient + separate step."""
+    from sparsify_amd import ops
+    torch.manual_seed(N + D + M)
+    idx = dev(torch.stack([torch.randperm(M)[:k] for _ in range(N)]))
+    coeff = dev(torch.randn(N, k).to(torch.bfloat16))
+    rows = dev(torch.randn(N, D).to(rdtype))
+    shift = dev(torch.randn(D))
+    lr, beta, c = 3e-3, 0.95, 0.25
+    seg = ops.build_latent_segments(idx, M)
+    gW, gb, _ = ops.segmented_weight_grad(seg, coeff, rows, want_bias=True, row_shift=shift)
+    p0, z0 = dev(torch.randn(M, D)), dev(torch.randn(M, D))
+    sep, fused, zs, zf = p0.clone(), p0.clone(), z0.clone(), z0.clone()
+    sh_sep = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    sh_fused = torch.empty_like(sh_sep)
+    if sfree:
+        ops.schedulefree_signsgd_step_(sep, zs, gW, lr, beta, c, sh_sep)
+        _, part = ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused, lr, sh_fused, row_shift=shift,
+                                                     schedule_free=(zf, beta, c), coeff_sums=gb)
+        assert torch.equal(zs, zf)
+    else:
+        ops.signsgd_step_(sep, gW, lr, sh_sep)
+        _, part = ops.segmented_weight_grad_signsgd_(seg, coeff, rows, fused, lr, sh_fused, row_shift=shift, coeff_sums=gb)
+    assert torch.equal(sep, fused) and torch.equal(sh_sep.view(torch.int16), sh_fused.view(torch.int16))
+    nb = -(-M // 32)
+    pad = torch.zeros(nb * 32, D, dtype=torch.float64, device="cuda")
+    pad[:M] = gb.double()[:, None] * p0.double()
+    want = pad.view(nb, 32, D).sum(1)
+    assert part.shape == (nb, D)
+    torch.testing.assert_close(part.double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("skewed", [False, True])
 def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
     """W_dec gradient + d top_acts through the L2-sliced kernel with per-slice dot partials
