@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
         f4 A, B;
         to_lines(wn, A, B);
         if (!(SPHIP_FUSE_X & 1)) {
+            // (other cache policies on these stores, one box: nt 2.31 ms, sc1 nt 2.37, sc1 2.40, sc0 sc1 2.41, sc0 2.42)
             if (rowlive && colA < D) __builtin_nontemporal_store(A, reinterpret_cast<f4*>(gW + (int64_t)j * D + colA));
             if (rowlive && colB < D) __builtin_nontemporal_store(B, reinterpret_cast<f4*>(gW + (int64_t)j * D + colB));
         }
