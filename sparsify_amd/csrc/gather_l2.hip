@@ -8,7 +8,7 @@
 // for random rows. Here the working set of the moment is made to fit the 4 MiB L2 of an XCD:
 // the latents are cut into B blocks of BLOCK_ROWS rows, and a launch handles ONE latent block
 // for all tokens and all 128-byte column slices, the slices dealt to the XCDs, so that an XCD
-// gathers from BLOCK_ROWS x 128 B = 2 MiB of the table at a time. B launches follow each other
+// gathers from BLOCK_ROWS x 128 B (4 MiB) of the table at a time. B launches follow each other
 // on the stream; the first writes out = bias + partial sum, the others add theirs, so the
 // sum has a fixed order (block by block, slots in order inside a block) and needs no atomics.
 //
@@ -26,7 +26,16 @@ namespace sphip {
 
 void launch_exclusive_scan(unsigned* a, int64_t n, unsigned* chunk_tot, hipStream_t s);   // segments.hip
 
-constexpr int L2_BLOCK_ROWS = 16384;   // latents per block: 2 MiB of 128-byte row pieces
+// Latents per block. A block's 128-byte row pieces of one slice are what an XCD gathers from at a
+// time: 32768 rows = 4 MiB, the whole L2 -- more than fits beside the lists and the output, yet
+// measured fastest at the headline shape (make EXTRA=-DSPHIP_L2_BLOCK_ROWS=n, one box, M = 131072):
+// 12288 rows 3.68 ms, 16384 3.28, 20480 3.21, 24576 3.09, 28672 3.04, 32768 3.04, 43776 3.87.
+// Larger blocks mean fewer launches, each of which re-reads and re-writes the whole output
+// (four passes instead of eight), and longer lists per (token, block), i.e. fuller batches.
+#ifndef SPHIP_L2_BLOCK_ROWS
+#define SPHIP_L2_BLOCK_ROWS 32768
+#endif
+constexpr int L2_BLOCK_ROWS = SPHIP_L2_BLOCK_ROWS;
 constexpr int L2_MAX_BLOCKS = 32;
 constexpr int L2_STAGE = 2048;         // staged list entries per workgroup (16 KiB)
 
