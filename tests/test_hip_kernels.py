@@ -648,6 +648,27 @@ def test_auxk_compact_selection_equals_masked_topk(device, N, D, M, n_dead, k):
     assert torch.equal(acts.gather(-1, order_a).view(torch.int16), want_acts.gather(-1, order_b).view(torch.int16))
 
 
+@pytest.mark.parametrize("R,D,M", [(1, 4, 1), (37, 72, 200), (1000, 4096, 4096)])
+def test_scatter_rows_and_scatter_add_rows(device, R, D, M):
+    """sphip_scatter_rows: zeros with the listed rows set; sphip_scatter_add_rows: the listed
+    (distinct) rows incremented in place, everything else untouched -- both exact."""
+    from sparsify_amd import ops
+    torch.manual_seed(R + D + M)
+    rows = dev(torch.randperm(M)[:R].contiguous())
+    src = dev(torch.randn(R + 3, D))                                  # more rows than R: the tail is ignored
+    dense = ops.scatter_rows(src, rows, R, M)
+    want = torch.zeros(M, D, device="cuda")
+    want[rows] = src[:R]
+    assert torch.equal(dense, want)
+    base = dev(torch.randn(M, D))
+    got = ops.scatter_add_rows_(base.clone(), src, rows, R)
+    want = base.clone()
+    want[rows] += src[:R]
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.scatter_add_rows_(base.clone(), src[:, : D // 2 or 1].contiguous() if D > 1 else src[:0], rows, R)
+
+
 @pytest.mark.parametrize("skewed", [False, True])
 @pytest.mark.parametrize("rdtype", [torch.bfloat16, torch.float32])
 def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, skewed, rdtype):
