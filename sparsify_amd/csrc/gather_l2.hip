@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
     // piece of latent j: tcol + j * stride
     const float* tcol = SM ? table + ((int64_t)slice * M) * 32 + sub * 4 : table + col;
     const int64_t stride = SM ? 32 : D;
-    constexpr int U = 4;
+    // pieces in flight per lane group (make EXTRA=-DSPHIP_L2_U=n, 32768-row blocks): 3 -> 3.04 ms, 4 -> 3.03, 6 -> 2.99, 8 -> 3.10
+#ifndef SPHIP_L2_U
+#define SPHIP_L2_U 4
+#endif
+    constexpr int U = SPHIP_L2_U;
     auto run = [&](auto entry) {
         const int last = max(end - 1, 0);
         uint2 nxt[U];
