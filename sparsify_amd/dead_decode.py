@@ -79,6 +79,8 @@ class DeadLatentDecode(torch.autograd.Function):
     def forward(ctx, indices: Tensor, acts: Tensor, W_dec: Tensor, b_dec: Tensor, dead_list: Tensor,
                 slot_of: Tensor | None, num_dead: int):
         parallel.wait_for(W_dec)
+        # rows can only stay parked across passes when a backward pass died half-way: drop them
+        _pending_rows.pop(W_dec.data_ptr(), None)
         N = indices.shape[0]
         M, D = W_dec.shape
         Kd = -(-num_dead // 64) * 64
