@@ -40,8 +40,9 @@ def eligible(pre_acts: Tensor, k_aux: int, W_dec: Tensor, num_dead: int) -> bool
 # DeadLatentDecode.backward runs before the main decode's backward (it was recorded later); instead
 # of returning an (M, D) tensor that is zero outside the dead rows -- a 2 GiB fill plus an (M, D)
 # addition by the autograd engine at the headline shape, 1.6 ms -- it parks its (n_dead, D) rows
-# here, keyed by the parameter's storage address (validated through a weak reference), and utils.SparseDecode.backward adds them into the dense gradient
-# it returns (claim_pending_rows). A callback queued on the autograd engine settles whatever is
+# here, keyed by the parameter's storage address (validated through a weak reference), and
+# utils.SparseDecode.backward adds them into the dense gradient it returns (claim_pending_rows).
+# A callback queued on the autograd engine settles whatever is
 # still parked when the backward pass ends (no main decode in the graph): it then goes into
 # W_dec.grad directly.
 _pending_rows: dict[int, list] = {}
