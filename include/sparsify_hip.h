@@ -259,6 +259,16 @@ int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, int64_t D, v
 int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow,
                        void* stream);
 
+/* torch.optim.Adam's step (the "adam" optimizer of trainer.py:92-122 when bitsandbytes is absent:
+ * betas, eps, no weight decay, no amsgrad) for one parameter: exp_avg / exp_avg_sq / p updated in
+ * one pass, operations in the order of torch's single-tensor implementation, bias corrections
+ * 1 - beta^step and the scalars 1 - beta, lr / (1 - beta1^step) computed in double on the host
+ * (hence the double arguments) and rounded to fp32 once; `step` counts from 1. Optionally refreshes a bf16
+ * shadow of p in the same pass (bf16_shadow may be NULL). */
+int sphip_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, int64_t step, void* bf16_shadow,
+                    void* stream);
+
 /* trainer.py:513-518 fused for one decoder matrix: projected gradient (not written back)
  * followed by the SignSGD step on W, one pass over (W, G). renorm != 0 additionally applies
  * set_decoder_norm_to_unit_norm (sparse_coder.py:273-279) to the updated rows in the same

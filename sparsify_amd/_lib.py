@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 LIB_NAME = "libsparsify_hip.so"
@@ -21,7 +21,7 @@ class HipLibraryError(RuntimeError):
     """An entry point of libsparsify_hip.so returned a non-zero status."""
 
 
-_P, _I, _L, _F, _Z = c_void_p, c_int, c_int64, c_float, c_size_t
+_P, _I, _L, _F, _Z, _D = c_void_p, c_int, c_int64, c_float, c_size_t, c_double
 
 # name -> (restype, argtypes); mirrors include/sparsify_hip.h one to one
 SIGNATURES: dict[str, tuple] = {
@@ -73,6 +73,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_decoder_schedulefree_apply_signs": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P, _L, _L, _P]),
     "sphip_segmented_weight_grad_signsgd": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _F, _P, _P, _P, _P, _Z, _P]),
     "sphip_segmented_weight_grad_schedulefree": (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _L, _L, _L, _P, _P, _F, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "sphip_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _L, _P, _P]),
     "sphip_segment_coeff_sums": (_I, [_P, _P, _P, _I, _L, _P, _P]),
     "sphip_sign_i8": (_I, [_P, _L, _P, _P]),
     "sphip_decoder_project_sign_i8": (_I, [_P, _P, _L, _L, _P, _P]),

@@ -10,6 +10,7 @@
 // for the element-wise ones. The fused decoder update reads (W, G) once and writes W once
 // instead of the reference's einsum / sub / sign / add passes.
 #include "common.hpp"
+#include <math.h>
 
 namespace sphip {
 
@@ -711,6 +712,87 @@ extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr,
                   "signsgd_step: operands must be 16-byte aligned");
     hipLaunchKernelGGL(signsgd_kernel, dim3(flat_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, p, g, n, lr, (bf16_t*)bf16_shadow);
     SPHIP_CHECK_LAUNCH("signsgd_step");
+    return SPHIP_OK;
+}
+
+#ifndef SPHIP_ADAM_NT
+#define SPHIP_ADAM_NT 1
+#endif
+namespace sphip {
+// torch.optim.Adam's update (betas, eps, no weight decay, no amsgrad) in one pass over
+// (p, g, exp_avg, exp_avg_sq), optionally refreshing the bf16 shadow of p. The operations and
+// their order are those of torch's single-tensor implementation: m.lerp_(g, 1 - b1);
+// v.mul_(b2).addcmul_(g, g, 1 - b2); denom = sqrt(v) / sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr / bc1).
+__device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v, float w1, float b2, float w2,
+                                           float step_size, float bc2_sqrt, float eps) {
+    m = __fmaf_rn(w1, g - m, m);                           // lerp, weight < 0.5: start + weight * (end - start)
+    v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(w2, g), g));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+    p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));
+    return p;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float w1,
+                                                   float b2, float w2, float step_size, float bc2_sqrt, float eps,
+                                                   bf16_t* __restrict__ shadow) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // every stream is touched once per step and is far larger than the caches: non-temporal
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ldx = [](const float* q) {
+#if SPHIP_ADAM_NT
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(q));
+        return make_float4(t[0], t[1], t[2], t[3]);
+#else
+        return *reinterpret_cast<const float4*>(q);
+#endif
+    };
+    auto stx = [](float* q, float4 x) {
+#if SPHIP_ADAM_NT
+        const f4 t = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(q));
+#else
+        *reinterpret_cast<float4*>(q) = x;
+#endif
+    };
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P = ldx(p + i * 4), M = ldx(m + i * 4), V = ldx(v + i * 4);
+        const float4 G = ldx(g + i * 4);
+        adam_elem(P.x, G.x, M.x, V.x, w1, b2, w2, step_size, bc2_sqrt, eps);
+        adam_elem(P.y, G.y, M.y, V.y, w1, b2, w2, step_size, bc2_sqrt, eps);
+        adam_elem(P.z, G.z, M.z, V.z, w1, b2, w2, step_size, bc2_sqrt, eps);
+        adam_elem(P.w, G.w, M.w, V.w, w1, b2, w2, step_size, bc2_sqrt, eps);
+        stx(p + i * 4, P), stx(m + i * 4, M), stx(v + i * 4, V);
+        if (shadow != nullptr) *reinterpret_cast<uint2*>(shadow + i * 4) = pack_bf16x4(P);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float P = p[i], M = m[i], V = v[i];
+        adam_elem(P, g[i], M, V, w1, b2, w2, step_size, bc2_sqrt, eps);
+        p[i] = P, m[i] = M, v[i] = V;
+        if (shadow != nullptr) shadow[i] = f32_to_bf16(P);
+    }
+}
+}  // namespace sphip
+
+extern "C" int sphip_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                               double beta1, double beta2, double eps, int64_t step, void* bf16_shadow, void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(p && g && exp_avg && exp_avg_sq, SPHIP_EINVAL, "adam_step: null pointer");
+    SPHIP_REQUIRE(n > 0 && step >= 1, SPHIP_EINVAL, "adam_step: n and step must be positive");
+    SPHIP_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, SPHIP_EINVAL, "adam_step: bad hyperparameters");
+    SPHIP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                      ((uintptr_t)bf16_shadow & 7) == 0,
+                  SPHIP_EINVAL, "adam_step: operands must be 16-byte aligned");
+    // scalars in double as torch computes them on the host (1 - beta, 1 - beta ** step, lr / bc1),
+    // rounded to fp32 once, where torch hands them to its kernels
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps,
+                       (bf16_t*)bf16_shadow);
+    SPHIP_CHECK_LAUNCH("adam_step");
     return SPHIP_OK;
 }
 

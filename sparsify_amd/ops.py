@@ -630,6 +630,23 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
     return p
 
 
+def adam_step_(p: Tensor, g: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float,
+               eps: float, step: int, bf16_shadow: Tensor | None = None) -> Tensor:
+    """torch.optim.Adam's update of one parameter (no weight decay, no amsgrad), one pass; step counts from 1."""
+    for t, name in ((p, "param"), (g, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, name, torch.float32)
+        if t.shape != p.shape:
+            raise ValueError(f"adam_step: {name} shape mismatch")
+    if bf16_shadow is not None:
+        _req(bf16_shadow, "bf16_shadow", torch.bfloat16)
+    _ev = timer.start("sphip_adam_step", p)
+    check(_lib.load().sphip_adam_step(p.data_ptr(), g.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), p.numel(),
+                                     float(lr), float(beta1), float(beta2), float(eps), int(step), _ptr(bf16_shadow),
+                                     _stream(p)), "sphip_adam_step")
+    timer.stop(_ev, p)
+    return p
+
+
 def schedulefree_signsgd_step_(p: Tensor, z: Tensor, g: Tensor, lr: float, beta: float, c: float,
                                 bf16_shadow: Tensor | None = None) -> Tensor:
     """One pass of ScheduleFreeWrapper(SignSGD).step() over (p = y, z, g); see sparsify_hip.h."""

@@ -28,6 +28,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import ops, parallel
+from .adam import Adam
 from .config import TrainConfig
 from .muon import Muon
 from .schedule_free import ScheduleFreeWrapper
@@ -143,7 +144,7 @@ class Trainer:
         match cfg.optimizer:
             case "adam":
                 pgs = groups(lambda s: 2e-4 / (s.num_latents / (2**14)) ** 0.5)
-                adam = torch.optim.Adam(pgs, fused=self.device.type == "cuda")   # one multi-tensor kernel
+                adam = Adam(pgs)                   # one HIP pass per parameter, bf16 shadow included
                 self.optimizers = [adam]
                 self.lr_schedulers = [_linear_warmup_decay(adam, cfg.lr_warmup_steps, num_batches)]
             case "muon":
@@ -152,7 +153,7 @@ class Trainer:
                 rest = [p for p in params if p.ndim < 2]
                 self.optimizers = [
                     Muon(muon_params, lr=cfg.lr or 2e-3, ddp=not (cfg.distribute_modules or cfg.shard_latents)),
-                    torch.optim.Adam(rest, lr=cfg.lr or 2e-3),
+                    Adam(rest, lr=cfg.lr or 2e-3),
                 ]
                 self.lr_schedulers = [
                     _linear_warmup_decay(self.optimizers[0], 0, num_batches),

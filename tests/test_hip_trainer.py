@@ -395,3 +395,54 @@ def test_schedulefree_kernels_vs_independent_oracle(device, D):
     # .eval(): x = lerp(y, z, 1 - 1/beta) as schedule_free.ScheduleFreeWrapper.eval computes it
     x = torch.lerp(Ey, Ez, 1 - 1 / beta)
     torch.testing.assert_close(x.cpu().double(), ora_e.eval_weights(), rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096 + 3, 300_001])
+def test_adam_step_vs_torch_adam(device, n):
+    """sparsify_amd.adam.Adam (sphip_adam_step) against torch.optim.Adam (single-tensor, fp32, on the
+    CPU and on the GPU) over ten steps with a changing learning rate; the state dictionaries are
+    interchangeable, and the bf16 shadow is the rounded parameter, bit for bit. Tolerance: a few
+    ulp of fp32 per step (the only freedom is fused multiply-adds inside torch's own kernels)."""
+    import copy
+    from sparsify_amd import ops
+    from sparsify_amd.adam import Adam
+    gen = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=gen)
+    grads = [torch.randn(n, generator=gen) * (10.0 ** (i % 3 - 1)) for i in range(10)]
+    ours = torch.nn.Parameter(p0.clone().cuda())
+    refs = [torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone().cuda())]
+    opt = Adam([ours], lr=1e-3)
+    ropts = [torch.optim.Adam([r], lr=1e-3, foreach=False, fused=False) for r in refs]
+    for i, g in enumerate(grads):
+        for o in [opt] + ropts:
+            o.param_groups[0]["lr"] = 1e-3 * (i + 1) / 10
+        ours.grad = g.cuda()
+        opt.step()
+        for r, ro in zip(refs, ropts):
+            r.grad = g.to(r.device)
+            ro.step()
+            torch.testing.assert_close(ours.detach().cpu(), r.detach().cpu(), rtol=2e-6, atol=2e-7)
+    st, rst = opt.state[ours], ropts[0].state[refs[0]]
+    assert float(st["step"]) == float(rst["step"]) == 10
+    torch.testing.assert_close(st["exp_avg"].cpu(), rst["exp_avg"], rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(st["exp_avg_sq"].cpu(), rst["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # torch's optimizer continues from our state dictionary, and ours from torch's
+    cont = torch.nn.Parameter(ours.detach().clone())
+    copt = torch.optim.Adam([cont], lr=1e-3, foreach=False, fused=False)
+    copt.load_state_dict(copy.deepcopy(opt.state_dict()))      # (load_state_dict aliases tensors already in place)
+    back = Adam([torch.nn.Parameter(ours.detach().clone())], lr=1e-3)
+    back.load_state_dict(copy.deepcopy(copt.state_dict()))
+    g = torch.randn(n, generator=gen).cuda()
+    ours.grad, cont.grad = g, g.clone()
+    back.param_groups[0]["params"][0].grad = g.clone()
+    opt.step(), copt.step(), back.step()
+    torch.testing.assert_close(ours.detach(), cont.detach(), rtol=2e-6, atol=2e-7)
+    assert torch.equal(back.param_groups[0]["params"][0].detach(), ours.detach())
+    # shadow refreshed in the same pass
+    if n % 4 == 3:
+        p = p0.clone().cuda()
+        m, v, sh = torch.zeros_like(p), torch.zeros_like(p), torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        ops.adam_step_(p, grads[0].cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1, sh)
+        assert torch.equal(sh, p.bfloat16())
+        with pytest.raises(Exception):
+            ops.adam_step_(p, grads[0].cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0)
