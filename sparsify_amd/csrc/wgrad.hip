@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     __shared__ float sh_wp[FUSE ? 4 : 1][FUSE ? SLICE_COLS : 1];     // per-wave partials of gb^T W (bpart)
     __shared__ int sh_cnt;                                           // waves that have left theirs
     if (threadIdx.x < 33) sh_sb[threadIdx.x] = seg_begin[min((int)lblock * 32 + (int)threadIdx.x, M)];
-    if (FUSE && threadIdx.x == 0) sh_cnt = 0;
+    if ((FUSE || DOT) && threadIdx.x == 0) sh_cnt = 0;
     __syncthreads();
 #ifndef SPHIP_SLICED_SORT
 #define SPHIP_SLICED_SORT 1
@@ -314,6 +314,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
         }
     }
     float* sl = DOT ? slab + (int64_t)slice * E : nullptr;
+    // The 32 latents of a workgroup are consecutive, so their segments are one contiguous range
+    // of `packed` (~32 N k / M entries): it is staged in LDS with coalesced loads, one round
+    // trip for the whole workgroup, instead of every lane group fetching its entries 8 bytes at
+    // a time from the Infinity Cache once per batch (the entry list is re-read for every
+    // slice and does not stay in L2; that fetch, not the L2-resident row pieces, was what a
+    // batch waited for). Ranges beyond the staging area (skewed latents) read global memory.
+    constexpr int STAGE = 2048;                         // entries (16 KiB)
+    __shared__ uint2 sh_pk[STAGE];
+    const int rb = sh_sb[0], re = sh_sb[32];            // block-uniform
+    const bool staged = re - rb <= STAGE;
+#ifndef SPHIP_DOT_LDS
+#define SPHIP_DOT_LDS 2
+#endif
+    // DOT with a staged list: an entry's partial dot is parked in the LDS slot of the entry itself
+    // (read into registers a batch earlier, never read again) and the last wave to finish writes the
+    // workgroup's whole range of the slab as contiguous lines, instead of every lane group storing
+    // 16 bytes per batch (a sixth of the kernel's L2 requests)
+    const bool park = DOT && SPHIP_DOT_LDS != 0 && staged;
     // partial dots of the batch at positions p .. p + U - 1 (entries past `stop` are not stored)
     typedef typename Piece<RT>::Raw Raw;
     auto dots = [&](const Raw* v, int p, int stop, int count) {
@@ -333,21 +351,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
             d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true));
             mine_d = (sub == u) ? d : mine_d;
         }
-        if (sub < count && p + sub < stop) sl[p + sub] = mine_d;
+        if (sub < count && p + sub < stop) {
+            if (park) sh_pk[p + sub - rb].x = __float_as_uint(mine_d);
+            else sl[p + sub] = mine_d;
+        }
     };
     // `rows` is the slice-major copy: piece of token n = base + n * 128 B
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
-    // The 32 latents of a workgroup are consecutive, so their segments are one contiguous range
-    // of `packed` (~32 N k / M entries): it is staged in LDS with coalesced loads, one round
-    // trip for the whole workgroup, instead of every lane group fetching its entries 8 bytes at
-    // a time from the Infinity Cache once per batch (the entry list is re-read for every
-    // slice and does not stay in L2; that fetch, not the L2-resident row pieces, was what a
-    // batch waited for). Ranges beyond the staging area (skewed latents) read global memory.
-    constexpr int STAGE = 2048;                         // entries (16 KiB)
-    __shared__ uint2 sh_pk[STAGE];
-    const int rb = sh_sb[0], re = sh_sb[32];            // block-uniform
-    const bool staged = re - rb <= STAGE;
     if (staged) {
         for (int i = threadIdx.x; i < re - rb; i += 256) sh_pk[i] = packed[rb + i];
         __syncthreads();
@@ -412,6 +423,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     if (live && row_shift != nullptr) {
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = fmaf(-bsum, row_shift[col + c], acc[c]);
+    }
+    if (DOT && park) {                                   // block-uniform
+        // no workgroup barrier (the waves end at different times by design): every wave counts
+        // itself when its dots are parked, the one that counts last stores the range. Slots of
+        // latents left to the wide kernel still hold their entries: those positions of this slab
+        // are never read (seg_dcoeff_mixed_kernel takes them from the wide kernel's slab).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(&sh_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (prev == 3) {
+            for (int i = lane; i < re - rb; i += 64) {
+                const float d = __uint_as_float(sh_pk[i].x);
+                if (SPHIP_DOT_LDS == 2) __builtin_nontemporal_store(d, sl + rb + i);
+                else sl[rb + i] = d;
+            }
+        }
     }
     typedef float f4 __attribute__((ext_vector_type(4)));
     if constexpr (FUSE && C == 8) {
