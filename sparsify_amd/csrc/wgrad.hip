@@ -194,8 +194,11 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 // the partial dot product <rows[n, slice], W[j, slice]> of every entry in slab[slice][position]
 // (8-lane butterfly per entry, lanes 0..3 of a group store the four entries of a batch as 16
 // contiguous bytes); seg_dcoeff_bounded_kernel sums the slices in order.
+#ifndef SPHIP_DOT_WAVES
+#define SPHIP_DOT_WAVES 8
+#endif
 template <typename RT, bool FUSE = false, bool DOT = false, bool SFREE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 1, FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : (DOT ? SPHIP_DOT_WAVES : 1), FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
