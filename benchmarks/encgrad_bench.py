@@ -18,17 +18,19 @@ gv = torch.randn(N, k, device=dev, generator=g).to(torch.bfloat16)
 rows = torch.randn(N, D, device=dev, generator=g).to(torch.bfloat16)
 shift = torch.randn(D, device=dev, generator=g)
 seg = ops.build_latent_segments(idx, M)
+cs = torch.randn(M, device=dev, generator=g)          # the b_dec partial sums ride along, as in the train step
 res = []
 for rnd in range(3):
-    ops.segmented_weight_grad_signsgd_(seg, gv, rows, W, 1e-4, shadow, row_shift=shift)
+    out = ops.segmented_weight_grad_signsgd_(seg, gv, rows, W, 1e-4, shadow, row_shift=shift, coeff_sums=cs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        ops.segmented_weight_grad_signsgd_(seg, gv, rows, W, 1e-4, shadow, row_shift=shift)
+        out = ops.segmented_weight_grad_signsgd_(seg, gv, rows, W, 1e-4, shadow, row_shift=shift, coeff_sums=cs)
     e1.record()
     torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / 5)
 res.sort()
 print(f"fused encoder gradient: median {res[1]:.3f} ms (min {res[0]:.3f})  {N * k * D * 2 / res[1] / 1e6:.0f} GB/s of row reads",
       flush=True)
+print("checksums:", float(W.double().sum()), float(shadow.double().sum()), float(out[1].double().sum()), flush=True)
