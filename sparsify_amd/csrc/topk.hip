@@ -29,6 +29,13 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+#ifndef SPHIP_TOPK_U
+#define SPHIP_TOPK_U 4         // block loads in flight per lane on the four-wave path (6: no gain, 8 spills)
+#endif
+#ifndef SPHIP_TOPK_REGS
+#define SPHIP_TOPK_REGS 1
+#endif
+
 namespace sphip {
 
 constexpr int TK_THREADS = 1024;   // threads per row, general instantiation
@@ -172,9 +179,19 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
         };
         if (by_tile) {
             // list of the blocks that can hold a candidate
-            for (int t0 = 0; t0 < T_; t0 += TK_THREADS) {
+            // (up to TK_GROUPS chunks: a thread's group maxima are the block maxima it loaded, no reload)
+            const bool in_regs = SPHIP_TOPK_REGS && T_ <= TK_GROUPS * TK_THREADS;
+            int c = 0;
+            for (int t0 = 0; t0 < T_; t0 += TK_THREADS, ++c) {
                 const int t = t0 + tid;
-                const bool hit = t < T_ && to_key(tm_row[t * 64]) >= tau;
+                unsigned mkey = 0;
+                if (in_regs) {
+#pragma unroll
+                    for (int r = 0; r < TK_GROUPS; ++r) mkey = (r == c) ? tmax[r] : mkey;
+                } else if (t < T_) {
+                    mkey = to_key(tm_row[t * 64]);
+                }
+                const bool hit = t < T_ && mkey >= tau;
                 const unsigned long long m = __ballot(hit);
                 if (m == 0ull) continue;
                 unsigned base = 0;
@@ -194,22 +211,31 @@ __global__ __launch_bounds__(TK_THREADS, 8) void topk_kernel(const T* __restrict
                 constexpr int GPW = 64 / LPT;             // blocks per wave instruction
                 // U block loads per lane are issued before the first candidate is pushed (the
                 // list's ballots and LDS atomics would otherwise serialise the loads' latencies)
-                constexpr int U = TK_THREADS >= 1024 ? 1 : 4;
+                // (kept as the 16 bytes they arrive in and widened to keys when they are pushed: with
+                // more of them in flight per lane, SPHIP_TOPK_U = 6, measured no faster)
+                constexpr int U = TK_THREADS >= 1024 ? 1 : SPHIP_TOPK_U;
                 for (unsigned g0 = (unsigned)wave * GPW; g0 < nt; g0 += U * TK_WAVES * GPW) {
-                    unsigned key[U][V];
-                    int at[U];
+                    uint4 raw[U];
+                    auto where = [&](int u) {              // first element of this lane's 16 bytes, M if none
+                        const unsigned g = g0 + (unsigned)(u * TK_WAVES * GPW) + (unsigned)(lane / LPT);
+                        return g < nt ? (int)tiles[g] * TK_TILE + (lane % LPT) * V : M;
+                    };
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const unsigned g = g0 + (unsigned)(u * TK_WAVES * GPW) + (unsigned)(lane / LPT);
-                        at[u] = g < nt ? (int)tiles[g] * TK_TILE + (lane % LPT) * V : M;
-                        if (at[u] < M) load_keys<T, true>(row, nullptr, at[u], M, key[u]);
+                        const int at = where(u);
+                        raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (at < M) raw[u] = *reinterpret_cast<const uint4*>(row + at);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (g0 + (unsigned)(u * TK_WAVES * GPW) >= nt) break;      // wave-uniform
+                        const int at = where(u);
+                        const T* e = reinterpret_cast<const T*>(&raw[u]);
 #pragma unroll
-                        for (int j = 0; j < V; ++j)
-                            push(at[u] < M && key[u][j] >= tau, at[u] < M ? key[u][j] : 0u, at[u] + j);
+                        for (int j = 0; j < V; ++j) {
+                            const unsigned key = at < M ? to_key(e[j]) : 0u;
+                            push(at < M && key >= tau, key, at + j);
+                        }
                     }
                 }
             }
