@@ -164,6 +164,26 @@ def test_topk_ties_and_degenerate_rows(device, dtype):
     assert torch.equal(v2, vals) and torch.equal(i2, idx)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,k", [(13120, 2048), (16384, 1024), (8192, 512), (4096, 2048), (2056, 300), (8, 8)])
+def test_topk_register_resident_exact_path(device, monkeypatch, dtype, M, k):
+    """Short rows with a large k (the compact AuxK selection) take topk_resident_kernel when the row
+    fits the workgroup's registers: values and indices position for position those of the sweeping
+    exact path of topk_kernel (SPHIP_TOPK_NO_RESIDENT=1), random rows and rows full of ties."""
+    from sparsify_amd import ops
+    torch.manual_seed(M + k)
+    rows = [torch.randn(M).clamp_min(0) for _ in range(5)] + [
+        torch.zeros(M), torch.full((M,), 3.0), torch.randint(0, 4, (M,)).float(), -torch.rand(M),
+        torch.arange(M, dtype=torch.float32) / 64, torch.randn(M).clamp_min(0) * (torch.rand(M) < 0.01)]
+    pre = torch.stack(rows).to(dtype)
+    vals, idx = ops.topk(dev(pre), k)
+    check_topk(pre, k, vals, idx)
+    monkeypatch.setenv("SPHIP_TOPK_NO_RESIDENT", "1")
+    v0, i0 = ops.topk(dev(pre), k)
+    assert torch.equal(i0, idx) and torch.equal(v0.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                                                vals.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+
+
 def _block_maxima(pre, tile=128):
     """tile_max in the layout sphip_encoder_preacts writes: [n // 64, t, n % 64]."""
     N, M = pre.shape
