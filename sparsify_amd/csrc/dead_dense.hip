@@ -15,37 +15,75 @@
 // scatter of the selected activations into A and A^T, the split + transpose of an fp32 matrix
 // into bf16 terms, and the scatter of the gradient rows back into the dense (M, D) gradient.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sphip {
 
 // ---------------------------------------------------------------- dead mask -> slots
-// One workgroup: thread t owns a contiguous run of latents, counts its dead ones, an
-// LDS scan gives the run's first slot. slot_of[m] = slot or -1; list[slot] = m.
+// One workgroup: thread t owns a contiguous run of 16-latent chunks (16 mask bytes per load), counts
+// its dead ones, a wave scan plus the 16 wave totals give the run's first slot, and a second pass
+// over the (cache-resident) mask writes slot_of[m] = slot or -1, 16 at a time, and list[slot] = m.
+__device__ __forceinline__ uint4 mask_chunk(const uint8_t* __restrict__ mask, int m0, int M, bool aligned) {
+    if (aligned && m0 + 16 <= M) return *reinterpret_cast<const uint4*>(mask + m0);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    for (int b = 0; b < 16 && m0 + b < M; ++b) w[b >> 2] |= (mask[m0 + b] != 0 ? 1u : 0u) << (8 * (b & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ int nonzero_bytes(unsigned w) {
+    w |= w >> 4;
+    w |= w >> 2;
+    w |= w >> 1;
+    return __popc(w & 0x01010101u);
+}
+
 __global__ __launch_bounds__(1024) void dead_compact_kernel(const uint8_t* __restrict__ mask, int M,
                                                             int* __restrict__ slot_of, int64_t* __restrict__ list,
                                                             int list_cap) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int per = (M + 1023) / 1024;
-    const int lo = min(t * per, M), hi = min(lo + per, M);
+    __shared__ int wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool aligned = ((uintptr_t)mask & 15) == 0;
+    const bool aligned_out = ((uintptr_t)slot_of & 15) == 0;
+    const int nchunks = (M + 15) / 16;
+    const int per = (nchunks + 1023) / 1024;
+    const int c_lo = min(t * per, nchunks), c_hi = min(c_lo + per, nchunks);
     int c = 0;
-    for (int m = lo; m < hi; ++m) c += mask[m] != 0;
-    part[t] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        const uint4 v = mask_chunk(mask, ch * 16, M, aligned);
+        c += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
     }
-    int s = part[t] - c;
-    for (int m = lo; m < hi; ++m) {
-        if (mask[m] != 0) {
-            slot_of[m] = s;
-            if (s < list_cap) list[s] = m;
-            ++s;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int s = incl - c;
+    for (int w = 0; w < wave; ++w) s += wave_tot[w];
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        const int m0 = ch * 16;
+        const uint4 v = mask_chunk(mask, m0, M, aligned);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        int out[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const bool dead = ((w[b >> 2] >> (8 * (b & 3))) & 0xffu) != 0u;
+            out[b] = dead ? s : -1;
+            if (dead) {
+                if (s < list_cap) list[s] = m0 + b;
+                ++s;
+            }
+        }
+        if (aligned_out && m0 + 16 <= M) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<int4*>(slot_of + m0 + 4 * q) = make_int4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
         } else {
-            slot_of[m] = -1;
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                if (m0 + b < M) slot_of[m0 + b] = out[b];
         }
     }
 }
@@ -68,6 +106,56 @@ __global__ __launch_bounds__(256) void dead_scatter_kernel(const int64_t* __rest
     At[(int64_t)s * ldT + n] = a;
 }
 
+// The same matrices without 2-byte scatters into global memory: a workgroup composes one token's row
+// of A in LDS (zero, scatter, one coalesced copy out; columns Kd .. ldA - 1 are zeroed too) ...
+__global__ __launch_bounds__(256) void dead_rows_kernel(const int64_t* __restrict__ idx, const bf16_t* __restrict__ acts,
+                                                        const int* __restrict__ slot_of, int k, int M, int Kd,
+                                                        int64_t ldA, bf16_t* __restrict__ A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    bf16_t* rowbuf = reinterpret_cast<bf16_t*>(dyn_smem);
+    const int64_t n = blockIdx.x;
+    const int chunks = (int)(ldA / 8);                                  // 16-byte chunks of the row, padding included
+    for (int c = threadIdx.x; c < chunks; c += 256) reinterpret_cast<uint4*>(rowbuf)[c] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (int e = threadIdx.x; e < k; e += 256) {
+        const int64_t j = idx[n * k + e];
+        if (j < 0 || j >= M) continue;
+        const int s = slot_of != nullptr ? slot_of[j] : (int)j;
+        if (s >= 0 && s < Kd) rowbuf[s] = acts[n * k + e];
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(A + n * ldA);
+    for (int c = threadIdx.x; c < chunks; c += 256) dst[c] = reinterpret_cast<const uint4*>(rowbuf)[c];
+}
+
+// ... and A^T is its transpose, 64 tokens x 128 slots per workgroup through LDS: reads run along the
+// slots (4 bytes per lane), writes along the tokens (4 bytes per lane, 128-byte row pieces). Tokens
+// N .. ldT - 1 (padding of A^T's rows) are written as zeros.
+__global__ __launch_bounds__(256) void transpose_u16_kernel(const bf16_t* __restrict__ A, int64_t N, int Kd, int64_t ldA,
+                                                            int64_t ldT, bf16_t* __restrict__ At) {
+    __shared__ bf16_t tile[64][130];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t n = n0 + i;
+        const int sc = s0 + 2 * tx;
+        unsigned v = 0u;
+        if (n < N && sc < Kd) v = *reinterpret_cast<const unsigned*>(A + n * ldA + sc);     // Kd, ldA even
+        tile[i][2 * tx] = (bf16_t)(v & 0xffffu);
+        tile[i][2 * tx + 1] = (bf16_t)(v >> 16);
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (int r = r0; r < 128; r += 8) {
+        const int sr = s0 + r;
+        const int64_t n = n0 + 2 * l;
+        if (sr >= Kd || n >= ldT) continue;
+        const unsigned v = (unsigned)tile[2 * l][r] | ((unsigned)tile[2 * l + 1][r] << 16);
+        *reinterpret_cast<unsigned*>(At + (int64_t)sr * ldT + n) = v;                          // ldT even
+    }
+}
+
 // ---------------------------------------------------------------- fp32 -> 3 bf16 terms, transposed
 __device__ __forceinline__ bf16_t split_term(float& r) {
     const bf16_t h = f32_to_bf16(r);
@@ -77,7 +165,8 @@ __device__ __forceinline__ bf16_t split_term(float& r) {
 
 // src: fp32 rows of C columns, row r = list ? list[r] : r for r < R (rows R..ldr-1 of the output
 // are zero padding). dst_p[c * ldr + r] = p-th bf16 term of src[row r][c]. 64 x 64 tiles
-// through LDS: reads run along c, writes along r.
+// through LDS: reads run along c, writes along r. (A 128 x 64 tile form writing two rows per lane,
+// 4-byte stores, measured slower: 0.56 against 0.39 ms for the two calls of the AuxK step.)
 __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ src,
                                                               const int64_t* __restrict__ list, int64_t R, int C,
                                                               int64_t ldr, bf16_t* __restrict__ d0,
@@ -170,7 +259,7 @@ using namespace sphip;
 
 extern "C" int sphip_dead_compact(const uint8_t* mask, int64_t M, int32_t* slot_of, int64_t* dead_list,
                                   int64_t list_capacity, void* stream) {
-    SPHIP_REQUIRE(mask && slot_of && dead_list, SPHIP_EINVAL, "dead_compact: null pointer");
+    SPHIP_REQUIRE(mask && slot_of && (dead_list || list_capacity == 0), SPHIP_EINVAL, "dead_compact: null pointer");
     SPHIP_REQUIRE(M > 0 && M < (1ll << 31) && list_capacity >= 0 && list_capacity < (1ll << 31), SPHIP_EINVAL,
                   "dead_compact: bad sizes M=%lld capacity=%lld", (long long)M, (long long)list_capacity);
     hipLaunchKernelGGL(dead_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, (int)M, slot_of,
@@ -187,6 +276,19 @@ extern "C" int sphip_dead_scatter_acts(const int64_t* idx, const void* acts_bf16
                   SPHIP_EINVAL, "dead_scatter_acts: bad sizes N=%lld k=%lld Kd=%lld ldA=%lld ldT=%lld", (long long)N,
                   (long long)k, (long long)Kd, (long long)ldA, (long long)ldT);
     hipStream_t s = (hipStream_t)stream;
+    // rows composed in LDS + a tiled transpose (0.81 -> see DESIGN) when a row fits 64 KiB of LDS
+    const bool composed = ldA * 2 <= 65536 && ldA % 8 == 0 && Kd % 2 == 0 && ldT % 2 == 0 && N < (1ll << 31) &&
+                          (((uintptr_t)A | (uintptr_t)At) & 15) == 0 && cdiv(Kd, 128) < 65536 &&
+                          getenv("SPHIP_DEAD_SCATTER") == nullptr;
+    if (composed) {
+        hipLaunchKernelGGL(dead_rows_kernel, dim3((unsigned)N), dim3(256), (size_t)(ldA * 2), s, idx, (const bf16_t*)acts_bf16,
+                           slot_of, (int)k, (int)M, (int)Kd, ldA, (bf16_t*)A);
+        SPHIP_CHECK_LAUNCH("dead_scatter_acts(rows)");
+        hipLaunchKernelGGL(transpose_u16_kernel, dim3((unsigned)cdiv(ldT, 64), (unsigned)cdiv(Kd, 128)), dim3(256), 0, s,
+                           (const bf16_t*)A, N, (int)Kd, ldA, ldT, (bf16_t*)At);
+        SPHIP_CHECK_LAUNCH("dead_scatter_acts(transpose)");
+        return SPHIP_OK;
+    }
     SPHIP_REQUIRE(hipMemsetAsync(A, 0, (size_t)(N * ldA * 2), s) == hipSuccess &&
                       hipMemsetAsync(At, 0, (size_t)(Kd * ldT * 2), s) == hipSuccess,
                   SPHIP_ELAUNCH, "dead_scatter_acts: memset failed");

@@ -601,9 +601,9 @@ def test_split_bf16_transposed_is_exact(device):
     src = torch.randn(R, C) * torch.logspace(-6, 6, C)
     src[5, 7] = 0.0
     rows = torch.randperm(R)[:150]
-    for lst, n_rows, ldr in ((None, R, 384), (rows, 150, 192)):
+    for lst, n_rows, ldr in ((None, R, 384), (rows, 150, 192), (None, R, 333), (rows, 150, 150), (rows, 129, 130)):
         parts = ops.split_bf16_transposed(dev(src), None if lst is None else dev(lst), n_rows, ldr).cpu()
-        want = (src if lst is None else src[lst]).T                                  # (C, n_rows)
+        want = (src if lst is None else src[lst[:n_rows]]).T                         # (C, n_rows)
         total = parts[0].double() + parts[1].double() + parts[2].double()
         assert torch.equal(total[:, :n_rows].float(), want)                         # 8 + 8 + 8 bits: exact
         assert torch.equal(parts[0][:, :n_rows], want.bfloat16())
@@ -884,3 +884,58 @@ def test_apply_signs_by_row_blocks_writes_the_slice_major_copy(device, schedule_
     assert torch.equal(buf, Wg.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
     with pytest.raises(ValueError):
         ops.decoder_apply_signs_(Wg[0:10], signs[0:10], 3e-3, True, slice_major=buf, row0=M - 5)
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 1000, 16400, 131071, 131072, 300_000])
+def test_dead_compact_any_length_and_alignment(device, M):
+    """sphip_dead_compact: slot_of / dead_list of a mask of any length, dense, sparse, empty and full,
+    also through a mask that does not start on a 16-byte boundary (the vector loads fall back)."""
+    from sparsify_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    for frac in (0.0, 0.1, 0.5, 1.0):
+        for shift in (0, 1):
+            base = torch.zeros(M + shift, dtype=torch.bool)
+            base[shift:] = torch.rand(M, generator=gen) < frac
+            dead = dev(base)[shift:]
+            want_list = base[shift:].nonzero().flatten()
+            n = int(want_list.numel())
+            slot_of, dead_list = ops.dead_compact(dead, n)
+            want_slot = torch.where(base[shift:], base[shift:].cumsum(0) - 1, torch.tensor(-1)).to(torch.int32)
+            assert torch.equal(slot_of.cpu(), want_slot) and torch.equal(dead_list.cpu(), want_list)
+
+
+@pytest.mark.parametrize("N,k,n_dead,M", [(100, 8, 40, 512), (64, 16, 64, 64), (257, 32, 700, 4096), (1, 4, 5, 32)])
+@pytest.mark.parametrize("mapped", [False, True])
+def test_dead_scatter_acts_composed_rows_equal_the_scatter(device, monkeypatch, N, k, n_dead, M, mapped):
+    """sphip_dead_scatter_acts: A (N, Kd) and A^T (Kd, ceil64 N) composed row by row in LDS and
+    transposed by tiles, against a dense torch construction and against the element-wise scatter
+    form (SPHIP_DEAD_SCATTER=1), bit for bit, padding included."""
+    from sparsify_amd import ops
+    gen = torch.Generator().manual_seed(N + k)
+    dead = torch.zeros(M, dtype=torch.bool)
+    dead[torch.randperm(M, generator=gen)[:n_dead]] = True
+    dead_ids = dead.nonzero().flatten()
+    pick = torch.stack([torch.randperm(n_dead, generator=gen)[:k] for _ in range(N)])       # distinct slots per token
+    acts = torch.randn(N, k, generator=gen).to(torch.bfloat16)
+    Kd = -(-n_dead // 64) * 64
+    if mapped:
+        slot_of, _ = ops.dead_compact(dev(dead), n_dead)
+        idx = dead_ids[pick]
+        if N > 2:
+            idx[1, 0] = -1                                    # inactive slot
+    else:
+        slot_of, idx = None, pick.clone()
+    want = torch.zeros(N, Kd, dtype=torch.bfloat16)
+    for n in range(N):
+        for e in range(k):
+            if idx[n, e] >= 0:
+                want[n, pick[n, e]] = acts[n, e]
+    A, At = ops.dead_scatter_acts(dev(idx), dev(acts), slot_of, Kd, num_valid=n_dead)
+    assert torch.equal(A.cpu().view(torch.int16), want.view(torch.int16))
+    ldT = -(-N // 64) * 64
+    wantT = torch.zeros(Kd, ldT, dtype=torch.bfloat16)
+    wantT[:, :N] = want.T
+    assert torch.equal(At.cpu().view(torch.int16), wantT.view(torch.int16))
+    monkeypatch.setenv("SPHIP_DEAD_SCATTER", "1")
+    A2, At2 = ops.dead_scatter_acts(dev(idx), dev(acts), slot_of, Kd, num_valid=n_dead)
+    assert torch.equal(A2.view(torch.int16), A.view(torch.int16)) and torch.equal(At2.view(torch.int16), At.view(torch.int16))
