@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     // a time from the Infinity Cache once per batch (the entry list is re-read for every
     // slice and does not stay in L2; that fetch, not the L2-resident row pieces, was what a
     // batch waited for). Ranges beyond the staging area (skewed latents) read global memory.
-    constexpr int STAGE = 2048;                         // entries (16 KiB)
+#ifndef SPHIP_SLICED_STAGE
+#define SPHIP_SLICED_STAGE 2048
+#endif
+    constexpr int STAGE = SPHIP_SLICED_STAGE;           // entries (16 KiB)
     __shared__ uint2 sh_pk[STAGE];
     const int rb = sh_sb[0], re = sh_sb[32];            // block-uniform
     const bool staged = re - rb <= STAGE;
