@@ -26,3 +26,7 @@ for s in range(steps):
         print(f"step {s + 1}: fvu {info.get('fvu/h'):.4f} auxk {info.get('auxk/h', 0.0):.4f} dead {info.get('dead_pct/h'):.3f} "
               f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB  {(time.perf_counter() - t0) / (s + 1) * 1e3:.1f} ms/step",
               flush=True)
+torch.cuda.synchronize()
+sae = tr.saes["h"]
+sums = [float(p.detach().double().sum()) for p in (sae.encoder.weight, sae.encoder.bias, sae.W_dec, sae.b_dec)]
+print("parameter checksums (two runs of the same command must print the same line):", " ".join(f"{v:.10e}" for v in sums), flush=True)
