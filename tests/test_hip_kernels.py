@@ -904,7 +904,9 @@ def test_dead_compact_any_length_and_alignment(device, M):
             assert torch.equal(slot_of.cpu(), want_slot) and torch.equal(dead_list.cpu(), want_list)
 
 
-@pytest.mark.parametrize("N,k,n_dead,M", [(100, 8, 40, 512), (64, 16, 64, 64), (257, 32, 700, 4096), (1, 4, 5, 32)])
+@pytest.mark.parametrize("N,k,n_dead,M", [(100, 8, 40, 512), (64, 16, 64, 64), (257, 32, 700, 4096), (1, 4, 5, 32),
+                                          (9, 16, 32760, 40000),      # a row of A fills the 64 KiB of LDS exactly
+                                          (9, 16, 33000, 40000)])     # one more tile of slots: the scatter form
 @pytest.mark.parametrize("mapped", [False, True])
 def test_dead_scatter_acts_composed_rows_equal_the_scatter(device, monkeypatch, N, k, n_dead, M, mapped):
     """sphip_dead_scatter_acts: A (N, Kd) and A^T (Kd, ceil64 N) composed row by row in LDS and
