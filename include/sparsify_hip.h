@@ -289,7 +289,7 @@ int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M, int64_t D
  * not part of the reference tree (parity unpinned; the host class schedule_free.py states the
  * algorithm it restates). The decoder form first projects g on the orthogonal complement of
  * the row (sparse_coder.py:281-295) and, with renorm != 0, normalises the new row
- * (sparse_coder.py:273-279); D <= 4096. slice_major: NULL, or the [D/32][M][32] copy of W
+ * (sparse_coder.py:273-279); D <= 8192. slice_major: NULL, or the [D/32][M][32] copy of W
  * (sphip_slice_major_f32) to rewrite with the finished rows in the same pass (D % 32 == 0). */
 int sphip_schedulefree_signsgd_step(float* p, float* z, const float* g, int64_t n, float lr,
                                     float beta, float c, void* bf16_shadow, void* stream);

@@ -882,8 +882,8 @@ extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const
     SPHIP_REQUIRE(W && Z && G, SPHIP_EINVAL, "decoder_schedulefree_signsgd_step: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
                   "decoder_schedulefree_signsgd_step: bad shape / beta");
-    SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 && ((uintptr_t)G & 15) == 0,
-                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_signsgd_step: needs D %% 4 == 0, D <= 4096, 16-byte aligned rows");
+    SPHIP_REQUIRE(D % 4 == 0 && D <= 8192 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 && ((uintptr_t)G & 15) == 0,
+                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_signsgd_step: needs D %% 4 == 0, D <= 8192, 16-byte aligned rows");
     SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0), SPHIP_EINVAL,
                   "decoder_schedulefree_signsgd_step: the slice-major copy needs D %% 32 == 0 and a 16-byte aligned buffer");
     hipStream_t s = (hipStream_t)stream;
@@ -893,13 +893,15 @@ extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const
         float* sm = slice_major;
         if (D <= 1024) hipLaunchKernelGGL((sf_decoder_kernel<1, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
         else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
-        else hipLaunchKernelGGL((sf_decoder_kernel<4, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
+        else if (D <= 4096) hipLaunchKernelGGL((sf_decoder_kernel<4, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
+        else hipLaunchKernelGGL((sf_decoder_kernel<8, true>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, sm, M);
         SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
         return SPHIP_OK;
     }
     if (D <= 1024) hipLaunchKernelGGL((sf_decoder_kernel<1>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_kernel<2>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
-    else hipLaunchKernelGGL((sf_decoder_kernel<4>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else if (D <= 4096) hipLaunchKernelGGL((sf_decoder_kernel<4>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
+    else hipLaunchKernelGGL((sf_decoder_kernel<8>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
     return SPHIP_OK;
 }
@@ -930,16 +932,17 @@ extern "C" int sphip_decoder_schedulefree_apply_signs(float* W, float* Z, const 
                   (long long)sm_rows);
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
                   "decoder_schedulefree_apply_signs: bad shape / beta");
-    SPHIP_REQUIRE(D % 4 == 0 && D <= 4096 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
+    SPHIP_REQUIRE(D % 4 == 0 && D <= 8192 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
                       ((uintptr_t)signs & 3) == 0,
-                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_apply_signs: needs D %% 4 == 0, D <= 4096, aligned rows");
+                  SPHIP_EUNSUPPORTED, "decoder_schedulefree_apply_signs: needs D %% 4 == 0, D <= 8192, aligned rows");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)M), block(256);
     const float wu = 1.f - 1.f / beta, wy = 1.f - beta;
     const signed char* t = (const signed char*)signs;
     if (D <= 1024) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<1>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
     else if (D <= 2048) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<2>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
-    else hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<4>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+    else if (D <= 4096) hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<4>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
+    else hipLaunchKernelGGL((sf_decoder_apply_signs_kernel<8>), grid, block, 0, s, W, Z, t, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS, slice_major, sm_rows, sm_row0);
     SPHIP_CHECK_LAUNCH("decoder_schedulefree_apply_signs");
     return SPHIP_OK;
 }

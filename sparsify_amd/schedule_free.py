@@ -137,7 +137,7 @@ class ScheduleFreeWrapper:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     return False
-                if group.get("project_rows", False) and (p.ndim != 2 or p.shape[1] % 4 or p.shape[1] > 4096):
+                if group.get("project_rows", False) and (p.ndim != 2 or p.shape[1] % 4 or p.shape[1] > 8192):
                     return False
         return True
 

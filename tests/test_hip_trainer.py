@@ -315,7 +315,7 @@ def test_trainer_grad_accumulation_and_k_decay(device):
     assert not torch.equal(tr.saes["h0"].encoder.weight, w0)
 
 
-@pytest.mark.parametrize("D", [64, 1024, 4096])
+@pytest.mark.parametrize("D", [64, 1024, 4096, 5120, 8192])
 def test_schedulefree_fused_step_equals_generic_path(device, monkeypatch, D):
     """ScheduleFreeWrapper(SignSGD): the one-kernel step (plain and decoder groups with projection
     + re-normalisation) against the generic multi-pass path of the same class."""
@@ -357,7 +357,7 @@ def test_schedulefree_fused_step_equals_generic_path(device, monkeypatch, D):
         assert bad.float().mean() < 2e-3
 
 
-@pytest.mark.parametrize("D", [64, 1000, 4096])
+@pytest.mark.parametrize("D", [64, 1000, 4096, 5120])
 def test_schedulefree_kernels_vs_independent_oracle(device, D):
     """sphip_schedulefree_signsgd_step / sphip_decoder_schedulefree_signsgd_step over ten steps against
     oracle/schedule_free_oracle.py, a float64 statement of the published algorithm that shares no
