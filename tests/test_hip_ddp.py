@@ -88,6 +88,43 @@ def test_two_rank_trainer_sign_exchange_equals_all_reduce(device):
     assert not torch.equal(r0[("signsgd", "overlap")]["W_dec"], r0[("signum", "overlap")]["W_dec"])
 
 
+def test_eight_rank_replicas_stay_identical(device):
+    """The same run with eight ranks on one GPU (gloo): the row-block and shard arithmetic of the sign
+    exchange at the world size of a full node (131072-row headline matrices split 8 x 8; here 4096 rows,
+    where the overlapped form falls back to two row blocks), early exchange of the decoder rows, the
+    bucketed bias reduction. Every rank must hold bit-identical parameters in every mode; the three
+    modes differ from one another only by the order in which eight summands are added."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank did not finish (collective mismatch?)")
+        assert p.exitcode == 0
+    r0 = ret[0]
+    for r in range(1, world):
+        for mode in r0.keys():
+            for name in r0[mode]:
+                if name == "fvu":
+                    assert r0[mode]["fvu"] == pytest.approx(ret[r][mode]["fvu"], rel=1e-6)
+                else:
+                    assert torch.equal(r0[mode][name], ret[r][mode][name]), f"rank {r} diverged: {name} ({mode})"
+    for opt in OPTIMIZERS:
+        for how in MODES:
+            assert r0[(opt, how)]["fvu"] < 1.0
+        # same update rule on the same mean gradient up to summation order: the runs stay close
+        a, b = r0[(opt, "allreduce")]["W_dec"], r0[(opt, "overlap")]["W_dec"]
+        assert ((a - b).abs() > 1e-6).float().mean() < 0.02
+
+
 def _rccl_one_rank(port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(0)
