@@ -21,6 +21,7 @@
 //                         without per-entry guards (as seg_wgrad_sliced_kernel, wgrad.hip)
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace sphip {
 
@@ -69,7 +70,10 @@ static bool l2_eligible(int64_t N, int64_t k, int64_t M, int64_t D) {
 // latent lies in block b. SCATTER = true (start now holds the scanned offsets): the slots are
 // written to their lists, in slot order. Slots with a negative or out-of-range index
 // (inactive: latent owned by another shard) belong to no block.
-template <typename CT, bool SCATTER>
+// PK4 (bf16 coefficients, blocks of at most 65536 rows): an entry is 4 bytes, the row inside its block
+// in the upper half and the coefficient's bf16 bits in the lower -- the lists are re-read once per
+// column slice (128 times at D = 4096), so their size is L2 fill traffic of the gather kernel.
+template <typename CT, bool SCATTER, bool PK4 = false>
 __global__ __launch_bounds__(256) void bucket_kernel(const int64_t* __restrict__ idx, const CT* __restrict__ coeff,
                                                      int64_t N, int k, int64_t M, int B, unsigned* __restrict__ start,
                                                      uint2* __restrict__ list) {
@@ -92,8 +96,14 @@ __global__ __launch_bounds__(256) void bucket_kernel(const int64_t* __restrict__
             }
             if (lane == b) mine += (unsigned)__popcll(m);
         }
-        if (SCATTER && bl >= 0)
-            list[pos] = make_uint2((unsigned)j, __float_as_uint(Elem<CT>::load(coeff, n * k + s)));
+        if (SCATTER && bl >= 0) {
+            if constexpr (PK4) {
+                reinterpret_cast<unsigned*>(list)[pos] = ((unsigned)(j - (int64_t)bl * L2_BLOCK_ROWS) << 16) |
+                                                         (unsigned)reinterpret_cast<const unsigned short*>(coeff)[n * k + s];
+            } else {
+                list[pos] = make_uint2((unsigned)j, __float_as_uint(Elem<CT>::load(coeff, n * k + s)));
+            }
+        }
     }
     if (!SCATTER && lane < B) start[(int64_t)lane * N + n] = mine;
 }
@@ -102,12 +112,12 @@ __global__ __launch_bounds__(256) void bucket_kernel(const int64_t* __restrict__
 // slice are then contiguous. In the row-major table they lie D*4 bytes apart, a power-of-two
 // stride that maps a latent block's pieces onto a few L2 sets (measured: L2 hit rate 27 %, the
 // gather then runs at the Infinity Cache's rate like the token-major kernels).
-template <bool FIRST, bool SM>
+template <bool FIRST, bool SM, bool PK4 = false>
 __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict__ list,
                                                         const unsigned* __restrict__ start,   // of this block
                                                         const float* __restrict__ table, const float* __restrict__ bias,
                                                         float* __restrict__ out, int N, int D, int64_t M,
-                                                        int groups_per_slice, int num_slices) {
+                                                        int groups_per_slice, int num_slices, unsigned row0 = 0) {
     // XCD-aware order: the workgroups of one XCD (same blockIdx % 8) walk slice after slice
     const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const unsigned slice = xcd + 8 * (local / (unsigned)groups_per_slice);
@@ -145,13 +155,23 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
     int beg = 0, end = 0;
     if (live) { beg = sh_sb[nl]; end = sh_sb[nl + 1]; }
 
-    __shared__ uint2 sh[L2_STAGE];
+    typedef typename std::conditional<PK4, unsigned, uint2>::type Entry;
+    const Entry* elist = reinterpret_cast<const Entry*>(list);
+    __shared__ Entry sh[L2_STAGE];
     const int rb = sh_sb[0], re = sh_sb[32];                             // block-uniform
     const bool staged = re - rb <= L2_STAGE;
     if (staged) {
-        for (int i = threadIdx.x; i < re - rb; i += 256) sh[i] = list[rb + i];
+        for (int i = threadIdx.x; i < re - rb; i += 256) sh[i] = elist[rb + i];
         __syncthreads();
     }
+    auto row_of = [&](Entry e) -> unsigned {
+        if constexpr (PK4) return row0 + (e >> 16);
+        else return e.x;
+    };
+    auto coeff_of = [&](Entry e) -> float {
+        if constexpr (PK4) return __uint_as_float(e << 16);
+        else return __uint_as_float(e.y);
+    };
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 prev = {0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -172,22 +192,22 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
     constexpr int U = SPHIP_L2_U;
     auto run = [&](auto entry) {
         const int last = max(end - 1, 0);
-        uint2 nxt[U];
+        Entry nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = entry(min(beg + u, last));
         int p = beg;
         for (; p + U <= end; p += U) {
-            uint2 pk[U];
+            Entry pk[U];
             float4 r[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
-            for (int u = 0; u < U; ++u) r[u] = load4(tcol + (int64_t)pk[u].x * stride);
+            for (int u = 0; u < U; ++u) r[u] = load4(tcol + (int64_t)row_of(pk[u]) * stride);
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float cf = __uint_as_float(pk[u].y);
+                const float cf = coeff_of(pk[u]);
                 acc[0] = fmaf(cf, r[u].x, acc[0]);
                 acc[1] = fmaf(cf, r[u].y, acc[1]);
                 acc[2] = fmaf(cf, r[u].z, acc[2]);
@@ -198,12 +218,12 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
             float4 r[U];
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
-                if (p + u < end) r[u] = load4(tcol + (int64_t)nxt[u].x * stride);
+                if (p + u < end) r[u] = load4(tcol + (int64_t)row_of(nxt[u]) * stride);
             }
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
                 if (p + u < end) {
-                    const float cf = __uint_as_float(nxt[u].y);
+                    const float cf = coeff_of(nxt[u]);
                     acc[0] = fmaf(cf, r[u].x, acc[0]);
                     acc[1] = fmaf(cf, r[u].y, acc[1]);
                     acc[2] = fmaf(cf, r[u].z, acc[2]);
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
     };
     if (end > beg) {
         if (staged) run([&](int pos) { return sh[pos - rb]; });
-        else run([&](int pos) { return list[pos]; });
+        else run([&](int pos) { return elist[pos]; });
     }
     if (live) {
         const f4 o = {prev[0] + acc[0], prev[1] + acc[1], prev[2] + acc[2], prev[3] + acc[3]};
@@ -263,8 +283,11 @@ extern "C" int sphip_gather_rows_weighted_l2(const int64_t* idx, const void* coe
     else
         hipLaunchKernelGGL((bucket_kernel<bf16_t, false>), tgrid, block, 0, s, idx, (const bf16_t*)coeff, N, (int)k, M, p.blocks, start, list);
     launch_exclusive_scan(start, cells, spine, s);
+    const bool pk4 = coeff_dtype == SPHIP_BF16 && L2_BLOCK_ROWS <= 65536 && getenv("SPHIP_L2_PK8") == nullptr;
     if (coeff_dtype == SPHIP_F32)
         hipLaunchKernelGGL((bucket_kernel<float, true>), tgrid, block, 0, s, idx, (const float*)coeff, N, (int)k, M, p.blocks, start, list);
+    else if (pk4)
+        hipLaunchKernelGGL((bucket_kernel<bf16_t, true, true>), tgrid, block, 0, s, idx, (const bf16_t*)coeff, N, (int)k, M, p.blocks, start, list);
     else
         hipLaunchKernelGGL((bucket_kernel<bf16_t, true>), tgrid, block, 0, s, idx, (const bf16_t*)coeff, N, (int)k, M, p.blocks, start, list);
     const int num_slices = (int)(D / 32);
@@ -276,8 +299,12 @@ extern "C" int sphip_gather_rows_weighted_l2(const int64_t* idx, const void* coe
     for (int b = 0; b < p.blocks; ++b) {
         const unsigned* st = start + (int64_t)b * N;
         dim3 grid((unsigned)nblocks);
+        const unsigned row0 = (unsigned)((int64_t)b * L2_BLOCK_ROWS);
 #define SPHIP_L2_LAUNCH(F, S) \
-    hipLaunchKernelGGL((gather_l2_kernel<F, S>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices)
+    do { \
+        if (pk4) hipLaunchKernelGGL((gather_l2_kernel<F, S, true>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
+        else hipLaunchKernelGGL((gather_l2_kernel<F, S, false>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
+    } while (0)
         if (b == 0 && sm) SPHIP_L2_LAUNCH(true, true);
         else if (b == 0) SPHIP_L2_LAUNCH(true, false);
         else if (sm) SPHIP_L2_LAUNCH(false, true);

@@ -244,7 +244,10 @@ class SparseCoder(nn.Module):
         """sparse_coder.py:198-202; the bias add is fused into the gather kernel."""
         assert self.W_dec is not None, "Decoder weight was not initialized."
         idx = top_indices.reshape(-1, top_indices.shape[-1]).contiguous()
-        acts = top_acts.to(self.dtype).reshape(-1, top_acts.shape[-1])
+        # (bf16 activations under autocast go to the kernels as they are: the cast to fp32 is exact and
+        # happens in registers, and 2-byte coefficients make the decode's slot lists 4-byte entries)
+        keep_bf16 = top_acts.dtype == torch.bfloat16 and self.W_dec.dtype == torch.float32
+        acts = (top_acts if keep_bf16 else top_acts.to(self.dtype)).reshape(-1, top_acts.shape[-1])
         y = SparseDecode.apply(idx, self.W_dec, acts, self.b_dec)
         return y.reshape(*top_indices.shape[:-1], self.d_in)
 
