@@ -14,6 +14,7 @@
 // The dot product for dcoeff is a 6-step wave reduction, no LDS, no barriers. Every output
 // row is written exactly once (zeros for empty segments), sums run in segment order.
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace sphip {
@@ -40,15 +41,22 @@ namespace sphip {
 // Segment-ordered entry list: packed[p] = {entry id e = perm[p], fp32 bits of coeff[e]}.
 // Turns the per-entry dependent gather (perm -> coeff) of the reduction kernels into one
 // sequential 8-byte stream; built once per call (N*k entries, a few tens of microseconds).
+// packed4 (bf16 coefficients, N <= 65536; may be null): the same entries as 4 bytes, token in the
+// upper half and the coefficient's bf16 bits in the lower, for the L2-sliced kernel with dots, which
+// re-reads the list once per column slice.
 template <typename CT>
 __global__ __launch_bounds__(256) void seg_pack_kernel(const unsigned* __restrict__ perm,
                                                        const CT* __restrict__ coeff, int64_t E,
                                                        const int* __restrict__ seg_begin, int M,
-                                                       uint2* __restrict__ packed, float* __restrict__ dcoeff) {
+                                                       uint2* __restrict__ packed, float* __restrict__ dcoeff,
+                                                       unsigned* __restrict__ packed4 = nullptr,
+                                                       FastDiv kdiv = FastDiv{}) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p < E) {
         const unsigned e = perm[p];
         packed[p] = make_uint2(e, __float_as_uint(Elem<CT>::load(coeff, e)));
+        if (sizeof(CT) == 2 && packed4 != nullptr)
+            packed4[p] = (fastdiv(e, kdiv) << 16) | (unsigned)reinterpret_cast<const unsigned short*>(coeff)[e];
         // entries past seg_begin[M] are inactive slots: no segment covers them
         if (dcoeff != nullptr && p >= seg_begin[M]) dcoeff[e] = 0.f;
     }
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 #ifndef SPHIP_DOT_WAVES
 #define SPHIP_DOT_WAVES 8
 #endif
-template <typename RT, bool FUSE = false, bool DOT = false, bool SFREE = false>
+template <typename RT, bool FUSE = false, bool DOT = false, bool SFREE = false, bool PK4 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : (DOT ? SPHIP_DOT_WAVES : 1), FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
@@ -327,7 +335,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
 #define SPHIP_SLICED_STAGE 2048
 #endif
     constexpr int STAGE = SPHIP_SLICED_STAGE;           // entries (16 KiB)
-    __shared__ uint2 sh_pk[STAGE];
+    // PK4: `packed` points at 4-byte entries (token << 16 | bf16 coefficient, seg_pack_kernel)
+    typedef typename std::conditional<PK4, unsigned, uint2>::type Entry;
+    const Entry* plist = reinterpret_cast<const Entry*>(packed);
+    __shared__ Entry sh_pk[STAGE];
+    auto token_of = [&](Entry e) -> unsigned {
+        if constexpr (PK4) return e >> 16;
+        else return fastdiv(e.x, kdiv);
+    };
+    auto coeff_of = [&](Entry e) -> float {
+        if constexpr (PK4) return __uint_as_float(e << 16);
+        else return __uint_as_float(e.y);
+    };
     const int rb = sh_sb[0], re = sh_sb[32];            // block-uniform
     const bool staged = re - rb <= STAGE;
 #ifndef SPHIP_DOT_LDS
@@ -358,7 +377,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
             mine_d = (sub == u) ? d : mine_d;
         }
         if (sub < count && p + sub < stop) {
-            if (park) sh_pk[p + sub - rb].x = __float_as_uint(mine_d);
+            if (park) {
+                if constexpr (PK4) sh_pk[p + sub - rb] = __float_as_uint(mine_d);
+                else sh_pk[p + sub - rb].x = __float_as_uint(mine_d);
+            }
             else sl[p + sub] = mine_d;
         }
     };
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     const RT* base = rows + ((int64_t)slice * N * 8 + sub) * C;
 
     if (staged) {
-        for (int i = threadIdx.x; i < re - rb; i += 256) sh_pk[i] = packed[rb + i];
+        for (int i = threadIdx.x; i < re - rb; i += 256) sh_pk[i] = plist[rb + i];
         __syncthreads();
     }
     // Software pipeline: the entries of batch b+1 are requested before the row pieces
@@ -381,23 +403,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     constexpr int U = FUSE ? SPHIP_FUSE_U : SPHIP_SLICED_U;
     auto run = [&](auto entry) {
         const int last = max(end - 1, 0);
-        uint2 nxt[U];
+        Entry nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = entry(min(beg + u, last));
         int p = beg;
         for (; p + U <= end; p += U) {
-            uint2 pk[U];
+            Entry pk[U];
             Raw v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) pk[u] = nxt[u];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = Piece<RT>::load(base + (int64_t)fastdiv(pk[u].x, kdiv) * (8 * C));
+            for (int u = 0; u < U; ++u) v[u] = Piece<RT>::load(base + (int64_t)token_of(pk[u]) * (8 * C));
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = entry(min(p + U + u, last));
             if (DOT) dots(v, p, end, U);
 #pragma unroll
             for (int u = 0; u < U; ++u) {      // the exact sequential fma chain of the full-row kernel
-                const float cf = __uint_as_float(pk[u].y);
+                const float cf = coeff_of(pk[u]);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, Piece<RT>::get(v[u], c), acc[c]);
                 bsum += cf;
@@ -408,13 +430,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
                 v[u] = Piece<RT>::zero();
-                if (p + u < end) v[u] = Piece<RT>::load(base + (int64_t)fastdiv(nxt[u].x, kdiv) * (8 * C));
+                if (p + u < end) v[u] = Piece<RT>::load(base + (int64_t)token_of(nxt[u]) * (8 * C));
             }
             if (DOT) dots(v, p, end, U - 1);
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
                 if (p + u < end) {
-                    const float cf = __uint_as_float(nxt[u].y);
+                    const float cf = coeff_of(nxt[u]);
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, Piece<RT>::get(v[u], c), acc[c]);
                     bsum += cf;
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     };
     if (end > beg) {
         if (staged) run([&](int pos) { return sh_pk[pos - rb]; });
-        else run([&](int pos) { return packed[pos]; });
+        else run([&](int pos) { return plist[pos]; });
     }
     if (live && row_shift != nullptr) {
 #pragma unroll
@@ -442,7 +464,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (prev == 3) {
             for (int i = lane; i < re - rb; i += 64) {
-                const float d = __uint_as_float(sh_pk[i].x);
+                float d;
+                if constexpr (PK4) d = __uint_as_float(sh_pk[i]);
+                else d = __uint_as_float(sh_pk[i].x);
                 if (SPHIP_DOT_LDS == 2) __builtin_nontemporal_store(d, sl + rb + i);
                 else sl[rb + i] = d;
             }
@@ -822,7 +846,7 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
                           float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr,
                           const float* Wdot = nullptr, float* slab = nullptr, SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f},
-                          const float* gb_in = nullptr, float* bpart = nullptr) {
+                          const float* gb_in = nullptr, float* bpart = nullptr, const unsigned* packed4 = nullptr) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -836,7 +860,12 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    if (FUSE && sf.z != nullptr)
+    if (DOT && !FUSE && packed4 != nullptr)
+        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, false, DOT, false, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s,
+                           reinterpret_cast<const uint2*>(packed4), seg,
+                           (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+    else if (FUSE && sf.z != nullptr)
         hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
                            shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
@@ -864,7 +893,9 @@ static void launch_nv(const uint2* packed, const int* seg, const void* rows, con
 
 }  // namespace sphip
 
-static size_t packed_bytes(int64_t N, int64_t k) { return (((size_t)N * (size_t)k * sizeof(uint2)) + 255) & ~(size_t)255; }
+static size_t packed8_bytes(int64_t N, int64_t k) { return (((size_t)N * (size_t)k * sizeof(uint2)) + 255) & ~(size_t)255; }
+// the 8-byte entries, then the same list as 4-byte entries (seg_pack_kernel: bf16 coefficients only)
+static size_t packed_bytes(int64_t N, int64_t k) { return packed8_bytes(N, k) + ((((size_t)N * (size_t)k * 4) + 255) & ~(size_t)255); }
 static size_t rows_sm_bytes(int64_t N, int64_t D) { return (size_t)N * (size_t)(((D * 4 + 127) / 128) * 128); }
 // the wide-sliced dcoeff path: D a multiple of 256 with at least two slices
 static bool wide_eligible(int64_t D) { return D % 256 == 0 && D >= 512 && D / 256 <= 65535; }
@@ -928,10 +959,13 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     const int64_t E = N * k;
     uint2* packed = (uint2*)workspace;
     void* rows_sm = (char*)workspace + packed_bytes(N, k);
+    // 4-byte entries for the L2-sliced kernel with dots (the W_dec gradient of a bf16-autocast step)
+    unsigned* packed4 = (coeff_dtype == SPHIP_BF16 && dot && rows_dtype == SPHIP_F32 && N <= 65536 && getenv("SPHIP_WGRAD_PK8") == nullptr)
+                            ? (unsigned*)((char*)workspace + packed8_bytes(N, k)) : nullptr;
     if (coeff_dtype == SPHIP_F32)
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, dcoeff);
     else
-        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, dcoeff);
+        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, dcoeff, packed4, make_fastdiv((unsigned)k));
     const char* force = getenv("SPHIP_WGRAD");     // "full" | "sliced" | "wide" (tests)
     // wide-sliced kernel: always for dcoeff at training sizes; without dcoeff only for long
     // segments (AuxK: N*k_aux entries over the few dead latents), where the 8-latents-per-wave
@@ -955,7 +989,8 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
             hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
         }
         if (launch_sliced<float, false, true>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M,
-                                              (int)D, s, 0.f, nullptr, skew, W, slab)) {
+                                              (int)D, s, 0.f, nullptr, skew, W, slab, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr,
+                                              nullptr, packed4)) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(l2 dot)");
             if (skew != nullptr) {
                 // (four column slices per launch, to keep the list's working set inside the
