@@ -31,6 +31,7 @@ namespace sphip {
 // A/B on one box (make EXTRA="-DSPHIP_FUSE_WAVES=w -DSPHIP_FUSE_U=u"): 5 waves x 4 pieces 2.65 ms,
 // 6 x 4 2.42, 7 x 3 2.38, 8 x 2 2.37 (7 x 4 and 8 x 4 spill: 2.46 / 2.81). The schedule-free form
 // (the z piece on top) is compiled for one wave less.
+// (with 4-byte list entries, PK4, the kernel needs four registers fewer and is compiled for one wave more)
 #ifndef SPHIP_FUSE_WAVES
 #define SPHIP_FUSE_WAVES 7
 #endif
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void slice_major_kernel(const RT* __restrict__
 #define SPHIP_DOT_WAVES 8
 #endif
 template <typename RT, bool FUSE = false, bool DOT = false, bool SFREE = false, bool PK4 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : (DOT ? SPHIP_DOT_WAVES : 1), FUSE ? SPHIP_FUSE_WAVES - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHIP_FUSE_WAVES + (PK4 ? 1 : 0) - (SFREE ? 1 : 0) : (DOT ? SPHIP_DOT_WAVES : 1), FUSE ? SPHIP_FUSE_WAVES + (PK4 ? 1 : 0) - (SFREE ? 1 : 0) : 8))) void seg_wgrad_sliced_kernel(const uint2* __restrict__ packed,
                                                                const int* __restrict__ seg_begin,
                                                                const RT* __restrict__ rows, float* __restrict__ gW,
                                                                float* __restrict__ gbias,
@@ -860,8 +861,13 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
     const int64_t rounds = cdiv(num_slices, 8);
     const int64_t nblocks = rounds * bps * 8;
     if (nblocks >= (1ll << 31)) return false;
-    if (DOT && !FUSE && packed4 != nullptr)
-        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, false, DOT, false, DOT>), dim3((unsigned)nblocks), dim3(256), 0, s,
+    if (packed4 != nullptr && FUSE && sf.z != nullptr)
+        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, FUSE, true>), dim3((unsigned)nblocks), dim3(256), 0, s,
+                           reinterpret_cast<const uint2*>(packed4), seg,
+                           (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+    else if (packed4 != nullptr)
+        hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            reinterpret_cast<const uint2*>(packed4), seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
                            shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
@@ -959,8 +965,8 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     const int64_t E = N * k;
     uint2* packed = (uint2*)workspace;
     void* rows_sm = (char*)workspace + packed_bytes(N, k);
-    // 4-byte entries for the L2-sliced kernel with dots (the W_dec gradient of a bf16-autocast step)
-    unsigned* packed4 = (coeff_dtype == SPHIP_BF16 && dot && rows_dtype == SPHIP_F32 && N <= 65536 && getenv("SPHIP_WGRAD_PK8") == nullptr)
+    // 4-byte entries for the L2-sliced kernels (bf16 coefficients: the activations of a bf16-autocast step)
+    unsigned* packed4 = (coeff_dtype == SPHIP_BF16 && N <= 65536 && getenv("SPHIP_WGRAD_PK8") == nullptr)
                             ? (unsigned*)((char*)workspace + packed8_bytes(N, k)) : nullptr;
     if (coeff_dtype == SPHIP_F32)
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, dcoeff);
@@ -1034,8 +1040,8 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
             hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
         }
         const bool done = rows_dtype == SPHIP_F32
-                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew)
-                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew);
+                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4)
+                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4);
         if (done) {
             if (skew != nullptr) {
                 const FastDiv kd = make_fastdiv((unsigned)k);
@@ -1102,10 +1108,13 @@ static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin
     const int64_t E = N * k;
     uint2* packed = (uint2*)workspace;
     void* rows_sm = (char*)workspace + packed_bytes(N, k);
+    // (bf16 coefficients -- the gradient of bf16 activations is bf16 -- also go out as 4-byte entries)
+    unsigned* packed4 = (coeff_dtype == SPHIP_BF16 && N <= 65536 && getenv("SPHIP_WGRAD_PK8") == nullptr)
+                            ? (unsigned*)((char*)workspace + packed8_bytes(N, k)) : nullptr;
     if (coeff_dtype == SPHIP_F32)
         hipLaunchKernelGGL((seg_pack_kernel<float>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const float*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
     else
-        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr);
+        hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr, packed4, make_fastdiv((unsigned)k));
     const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
     int* skew = (wide_eligible(D) && big) ? skew_word(workspace, N, k, D) : nullptr;
     if (skew != nullptr) {
@@ -1113,8 +1122,8 @@ static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin
         hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
     }
     const bool done = rows_dtype == SPHIP_F32
-                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials)
-                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials);
+                          ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials, packed4)
+                          : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials, packed4);
     SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
     if (skew != nullptr) {
         const FastDiv kd = make_fastdiv((unsigned)k);
