@@ -129,8 +129,19 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
                                                                    int D, float lr, float eps,
                                                                    float* __restrict__ sm = nullptr, int64_t M = 0) {
     __shared__ float red[16];
-    float* w = W + (int64_t)blockIdx.x * D;
-    const float* g = G + (int64_t)blockIdx.x * D;
+    // SPHIP_DEC_REMAP: workgroups are dealt to the XCDs round-robin, so rows j .. j+7 would run on eight
+    // different XCDs; with the remap one XCD's consecutive workgroups take eight adjacent rows, whose
+    // 128-byte pieces of a slice-major slice are 1 KiB contiguous behind one L2
+#ifndef SPHIP_DEC_REMAP
+#define SPHIP_DEC_REMAP 1
+#endif
+    int64_t row = blockIdx.x;
+    if (SPHIP_DEC_REMAP && SM && (gridDim.x & 63) == 0) {
+        const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        row = (int64_t)(local >> 3) * 64 + xcd * 8 + (local & 7);
+    }
+    float* w = W + row * D;
+    const float* g = G + row * D;
     float4 b[R], a[R];
     // every stream crosses the kernel once (two 2 GiB matrices in, one or two out): non-temporal
     // accesses, bits 1 / 2 / 4 / 8 = W load, G load, W store, slice-major store. A/B on one box
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
         if (c < D) {
             st(w + c, b[i], (SPHIP_DEC_NT & 4) != 0);
             // slice c4 / 8, piece of row blockIdx.x, chunk c4 % 8: eight threads write one 128-byte line
-            if (SM) st(sm + (((int64_t)(c4 >> 3) * M + blockIdx.x) * 8 + (c4 & 7)) * 4, b[i], (SPHIP_DEC_NT & 8) != 0);
+            if (SM) st(sm + (((int64_t)(c4 >> 3) * M + row) * 8 + (c4 & 7)) * 4, b[i], (SPHIP_DEC_NT & 8) != 0);
         }
     }
 }
