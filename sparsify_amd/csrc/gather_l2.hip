@@ -38,7 +38,10 @@ void launch_exclusive_scan(unsigned* a, int64_t n, unsigned* chunk_tot, hipStrea
 #endif
 constexpr int L2_BLOCK_ROWS = SPHIP_L2_BLOCK_ROWS;
 constexpr int L2_MAX_BLOCKS = 32;
-constexpr int L2_STAGE = 2048;         // staged list entries per workgroup (16 KiB)
+#ifndef SPHIP_L2_STAGE
+#define SPHIP_L2_STAGE 2048
+#endif
+constexpr int L2_STAGE = SPHIP_L2_STAGE;         // staged list entries per workgroup (16 KiB with 8-byte entries)
 
 struct L2Plan {
     int blocks;
@@ -112,7 +115,10 @@ __global__ __launch_bounds__(256) void bucket_kernel(const int64_t* __restrict__
 // slice are then contiguous. In the row-major table they lie D*4 bytes apart, a power-of-two
 // stride that maps a latent block's pieces onto a few L2 sets (measured: L2 hit rate 27 %, the
 // gather then runs at the Infinity Cache's rate like the token-major kernels).
-template <bool FIRST, bool SM, bool PK4 = false>
+// BIG: four times the staging area, for lists that would not fit otherwise (32 k / B entries per
+// workgroup: the 4k-row decode of multi-top-k); it costs occupancy, so short lists keep the small one
+// (headline decode 2.92 ms small / 3.17 ms big; multi-top-k's 4k decode 14.7 ms small / 9.5 ms big).
+template <bool FIRST, bool SM, bool PK4 = false, bool BIG = false>
 __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict__ list,
                                                         const unsigned* __restrict__ start,   // of this block
                                                         const float* __restrict__ table, const float* __restrict__ bias,
@@ -157,9 +163,10 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const uint2* __restrict_
 
     typedef typename std::conditional<PK4, unsigned, uint2>::type Entry;
     const Entry* elist = reinterpret_cast<const Entry*>(list);
-    __shared__ Entry sh[L2_STAGE];
+    constexpr int STAGE = BIG ? 4 * L2_STAGE : L2_STAGE;
+    __shared__ Entry sh[STAGE];
     const int rb = sh_sb[0], re = sh_sb[32];                             // block-uniform
-    const bool staged = re - rb <= L2_STAGE;
+    const bool staged = re - rb <= STAGE;
     if (staged) {
         for (int i = threadIdx.x; i < re - rb; i += 256) sh[i] = elist[rb + i];
         __syncthreads();
@@ -296,13 +303,16 @@ extern "C" int sphip_gather_rows_weighted_l2(const int64_t* idx, const void* coe
     SPHIP_REQUIRE(nblocks < (1ll << 31), SPHIP_EUNSUPPORTED, "gather_rows_weighted_l2: grid too large");
     const bool sm = table_slice_major != nullptr;
     const float* tb = sm ? table_slice_major : table;
+    // a workgroup's 32 tokens bring about 32 k / B entries: beyond the small staging area, take the big one
+    const bool big_stage = (32 * k / p.blocks) * 5 / 4 > L2_STAGE;
     for (int b = 0; b < p.blocks; ++b) {
         const unsigned* st = start + (int64_t)b * N;
         dim3 grid((unsigned)nblocks);
         const unsigned row0 = (unsigned)((int64_t)b * L2_BLOCK_ROWS);
 #define SPHIP_L2_LAUNCH(F, S) \
     do { \
-        if (pk4) hipLaunchKernelGGL((gather_l2_kernel<F, S, true>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
+        if (pk4 && big_stage) hipLaunchKernelGGL((gather_l2_kernel<F, S, true, true>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
+        else if (pk4) hipLaunchKernelGGL((gather_l2_kernel<F, S, true>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
         else hipLaunchKernelGGL((gather_l2_kernel<F, S, false>), grid, block, 0, s, list, st, tb, bias, out, (int)N, (int)D, M, gps, num_slices, row0); \
     } while (0)
         if (b == 0 && sm) SPHIP_L2_LAUNCH(true, true);

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
 #ifndef SPHIP_SLICED_STAGE
 #define SPHIP_SLICED_STAGE 2048
 #endif
-    constexpr int STAGE = SPHIP_SLICED_STAGE;           // entries (16 KiB)
+    constexpr int STAGE = PK4 ? 2 * SPHIP_SLICED_STAGE : SPHIP_SLICED_STAGE;   // entries (16 KiB either way)
     // PK4: `packed` points at 4-byte entries (token << 16 | bf16 coefficient, seg_pack_kernel)
     typedef typename std::conditional<PK4, unsigned, uint2>::type Entry;
     const Entry* plist = reinterpret_cast<const Entry*>(packed);
@@ -840,6 +840,12 @@ __global__ __launch_bounds__(256) void seg_dcoeff_mixed_kernel(const uint2* __re
 // segments longer than this go from the L2-sliced kernel to the wide kernel, whose waves (a small
 // fixed grid of LONG_GRID workgroups per column slice) walk the list of such latents
 constexpr int SKEW_T = 512;
+// without dots the wide (wave-per-latent) kernel takes over from the L2-sliced one when the mean segment
+// is this long (AuxK as row gathers: ~2500 entries on each dead latent); the multi-top-k decode
+// (mean 4 N k / M = 96 at the headline shape) stays with the L2-sliced kernel: 20.7 -> see DESIGN
+#ifndef SPHIP_WIDE_MEAN
+#define SPHIP_WIDE_MEAN 256
+#endif
 constexpr unsigned LONG_GRID = 256;
 
 template <typename RT, bool FUSE = false, bool DOT = false>
@@ -978,7 +984,7 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     // L2-sliced kernel would run one 8-lane group per wave
     const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
     const bool want_wide = dot ? ((force && force[0] == 's') || (big && N * k >= 4 * M))
-                               : ((force && force[0] == 'w') || (big && N * k >= 64 * M));
+                               : ((force && force[0] == 'w') || (big && N * k >= SPHIP_WIDE_MEAN * M));
     // dcoeff at training sizes with fp32 rows: the L2-sliced kernel with per-slice dot partials
     // (the N x 128 B slice of the rows stays in L2: twice the Infinity Cache's rate);
     // SPHIP_WGRAD=wide keeps the wide kernel (A/B), =l2 forces this one
