@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--workload", default="llama3-8b-layer d_in=4096 M=131072 k=192", choices=list(WORKLOADS))
     ap.add_argument("--cpu-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-auxk", action="store_true", help="skip the second (AuxK) run of the headline workload")
+    ap.add_argument("--no-auxk", action="store_true", help="skip the extra runs of the headline workload (AuxK, multi-top-k, signum, skewed usage)")
     ap.add_argument("--fp32", action="store_true", help="fp32 activations / no autocast (not the headline)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -230,11 +230,12 @@ def main():
     elapsed = float(t.item())
 
     headline = args.workload.startswith("llama3-8b-layer") and N == 16384 and not args.fp32 and not shard
-    auxk_ms = None
+    variants = {}
     if headline and world == 1 and not args.no_auxk and args.optimizer == "signsgd":
         del trainer, sae, batches
         torch.cuda.empty_cache()
-        auxk_ms = auxk_run(N, D, M, k, device)
+        for kind in ("auxk", "multitopk", "signum", "skewed"):
+            variants[kind] = variant_run(kind, N, D, M, k, device)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -303,8 +304,16 @@ def main():
                                "of L2 16.8-18.8 TB/s, Infinity Cache 7.4-8.6 TB/s, HBM 8.0 TB/s spec / 6.3 achievable); "
                                "profiled.counter_bytes = HBM-side FETCH_SIZE x2 + WRITE_SIZE of the same kernels in "
                                f"profiles/{prof_name}",
-            "extra": {"auxk_ms_per_step": auxk_ms,
-                      "auxk_note": "second run (SURVEY.md 8d): auxk_alpha = 1/32, 10 % of the latents dead, k_aux = 2048"},
+            "extra": {"auxk_ms_per_step": variants.get("auxk", {}).get("ms_per_step"),
+                      "auxk_note": "second run (SURVEY.md 8d): auxk_alpha = 1/32, 10 % of the latents dead, k_aux = 2048",
+                      "multitopk_ms_per_step": variants.get("multitopk", {}).get("ms_per_step"),
+                      "signum_ms_per_step": variants.get("signum", {}).get("ms_per_step"),
+                      "signum_note": "the reference's default optimizer (schedule-free SignSGD, third-party package: parity "
+                                     "unpinned); the headline runs plain SignSGD, which is pinned to sign_sgd.py",
+                      "skewed_ms_per_step": variants.get("skewed", {}).get("ms_per_step"),
+                      "skewed_usage": variants.get("skewed", {}).get("usage"),
+                      "skewed_note": "heavy-tailed latent usage (power-law atoms, coder planted with the dictionary) "
+                                     "instead of the flat usage of Gaussian rows; same step otherwise"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_tokens)
@@ -314,15 +323,25 @@ def main():
         dist.destroy_process_group()
 
 
-def auxk_run(N, D, M, k, device, steps: int = 4, warm: int = 2) -> float:
-    """The headline step with the AuxK term (sparse_coder.py:230-251): auxk_alpha = 1/32, about 10 %
-    of the latents held dead, k_aux = d_in / 2. Returns ms per step."""
+def variant_run(kind: str, N, D, M, k, device, steps: int = 4, warm: int = 2) -> dict:
+    """The headline step in one of its other forms; returns {"ms_per_step": ..., ...}.
+      auxk      the AuxK term (sparse_coder.py:230-251): auxk_alpha = 1/32, about 10 % of the latents held dead,
+                k_aux = d_in / 2 (the second run SURVEY.md 8d asks for)
+      multitopk the multi-top-k term (sparse_coder.py:256-262): a second decode over the 4k best latents
+      signum    the reference's default optimizer: schedule-free SignSGD (trainer.py:146-162; parity unpinned)
+      skewed    heavy-tailed latent usage instead of Gaussian rows' flat one: SyntheticActivations(skew="zipf"),
+                the coder planted with the dictionary (trainer.py here); reports the usage histogram too"""
     from sparsify_amd import SparseCoderConfig, TrainConfig
     from sparsify_amd.trainer import SyntheticActivations, Trainer
-    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", hookpoints=["h"], auxk_alpha=1 / 32,
-                      dead_feature_threshold=10**6, save_every=10**9, wandb_log_frequency=10**9, save_dir="")
-    src = SyntheticActivations(["h"], D, N, steps + warm, device=device)
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k, multi_topk=(kind == "multitopk")),
+                      optimizer="signum" if kind == "signum" else "signsgd", hookpoints=["h"],
+                      auxk_alpha=1 / 32 if kind == "auxk" else 0.0, dead_feature_threshold=10**6, save_every=10**9,
+                      wandb_log_frequency=10**9, save_dir="")
+    skew = dict(skew="zipf", atoms=M, draws=k) if kind == "skewed" else {}
+    src = SyntheticActivations(["h"], D, N, steps + warm, device=device, **skew)
     tr = Trainer(cfg, src, device=device)
+    if kind == "skewed":
+        src.plant(tr.saes["h"])
     dead = torch.rand(M, device=device, generator=torch.Generator(device=device).manual_seed(0)) < 0.10
     batches = [src.batch(s) for s in range(steps + warm)]
     t0 = 0.0
@@ -330,10 +349,22 @@ def auxk_run(N, D, M, k, device, steps: int = 4, warm: int = 2) -> float:
         if s == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        tr.num_tokens_since_fired["h"][dead] = 10**7          # these stay dead unless they fire
+        if kind == "auxk":
+            tr.num_tokens_since_fired["h"][dead] = 10**7          # these stay dead unless they fire
         tr.train_micro_batch(batches[s])
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    out = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3}
+    if kind == "skewed":
+        with torch.no_grad():
+            idx = tr.saes["h"].encode(batches[-1]["h"]).top_indices
+        cnt = torch.bincount(idx.flatten(), minlength=M)
+        f = cnt.float() / N
+        out["usage"] = {"latents_firing_on_over_10pct_of_tokens": int((f > 0.1).sum()), "over_1pct": int((f > 0.01).sum()),
+                        "never_in_this_batch": int((cnt == 0).sum()), "max_share_of_tokens": float(f.max()),
+                        "share_of_entries_in_segments_over_128": float(cnt[cnt > 128].sum() / cnt.sum())}
+    del tr, batches, src
+    torch.cuda.empty_cache()
+    return out
 
 
 def _fp32_forward(fwd, self, *a, **kw):

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
         // no workgroup barrier (the waves end at different times by design): every wave counts
         // itself when its dots are parked, the one that counts last stores the range. Slots of
         // latents left to the wide kernel still hold their entries: those positions of this slab
-        // are never read (seg_dcoeff_mixed_kernel takes them from the wide kernel's slab).
+        // are written again, with their partial dots, by seg_long_chunk_kernel, which runs after this kernel.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         int prev = 0;
         if (lane == 0) prev = __hip_atomic_fetch_add(&sh_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -602,18 +602,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     }
 }
 
-// gbias[j] = sum of the coefficients of latent j's segment, in segment order (the same chain as
-// bsum above): the bias gradient when the weight-gradient kernel runs fused with the optimizer
+// gbias[j] = sum of the coefficients of latent j's segment: the bias gradient, from this one kernel
+// whatever form computes the weight gradient (the forms' own coefficient sums only serve their row
+// shift). A segment of up to 64 entries is one sequential chain in segment order; a longer one is
+// summed by a whole wave -- lane l adds entries l, l + 64, ... in order, the 64 lane sums meet in the
+// xor butterfly -- so that a latent firing on thousands of tokens is not one thread's chain of
+// thousands of dependent gathers (1.4 ms at 7000 entries). Fixed by the segment alone either way.
 template <typename CT>
 __global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __restrict__ perm,
                                                             const int* __restrict__ seg_begin,
                                                             const CT* __restrict__ coeff, int M,
                                                             float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= M) return;
-    float t = 0.f;
-    for (int p = seg_begin[j]; p < seg_begin[j + 1]; ++p) t += Elem<CT>::load(coeff, perm[p]);
-    out[j] = t;
+    const int lane = threadIdx.x & 63;
+    int beg = 0, end = 0;
+    if (j < M) { beg = seg_begin[j]; end = seg_begin[j + 1]; }
+    const bool is_long = end - beg > 64;
+    if (j < M && !is_long) {
+        float t = 0.f;
+        int p = beg;
+        for (; p + 4 <= end; p += 4) {                     // four gathers in flight, added in order
+            const uint32_t e0 = perm[p], e1 = perm[p + 1], e2 = perm[p + 2], e3 = perm[p + 3];
+            const float c0 = Elem<CT>::load(coeff, e0), c1 = Elem<CT>::load(coeff, e1);
+            const float c2 = Elem<CT>::load(coeff, e2), c3 = Elem<CT>::load(coeff, e3);
+            t += c0, t += c1, t += c2, t += c3;
+        }
+        for (; p < end; ++p) t += Elem<CT>::load(coeff, perm[p]);
+        out[j] = t;
+    }
+    unsigned long long todo = __ballot(is_long);
+    while (todo != 0) {                                     // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int b = __shfl(beg, src, 64), e = __shfl(end, src, 64);
+        float t = 0.f;
+        for (int p = b + lane; p < e; p += 64) t += Elem<CT>::load(coeff, perm[p]);
+        t = wave_sum(t);
+        if (lane == 0) out[j + src] = t;                    // lane 0's latent is the wave's first
+    }
 }
 
 
@@ -634,43 +660,32 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
                                             const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
                                             int slice, int lane, float lr, bf16_t* __restrict__ shadow, SfArgs sf);
 
-template <typename RT, bool DOT, bool FUSE = false, bool LIST = false>
+template <typename RT, bool DOT, bool FUSE = false>
 __global__ __launch_bounds__(256) void seg_wgrad_wide_kernel(const uint2* __restrict__ packed,
                                                              const int* __restrict__ seg_begin,
                                                              const RT* __restrict__ rows,
                                                              const float* __restrict__ W, float* __restrict__ gW,
                                                              float* __restrict__ gbias, float* __restrict__ slab,
                                                              const float* __restrict__ row_shift, FastDiv kdiv,
-                                                             int64_t E, int M, int D,
-                                                             const int* __restrict__ skew = nullptr, int skew_T = 0,
-                                                             float lr = 0.f, bf16_t* __restrict__ shadow = nullptr,
-                                                             int slice0 = 0,
+                                                             int64_t E, int M, int D, float lr = 0.f,
+                                                             bf16_t* __restrict__ shadow = nullptr, int slice0 = 0,
                                                              SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f}) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slice = blockIdx.y + slice0;
-    if (LIST) {
-        // launched next to the L2-sliced kernel with a small fixed grid: the waves walk the list
-        // of long latents (skew[0] = their number, skew[1..] = the latents; usually empty)
-        const int n_long = skew[0];
-        for (int i = wv; i < n_long; i += (int)gridDim.x * 4)
-            wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D,
-                                       __builtin_amdgcn_readfirstlane(skew[1 + i]), slice, lane, lr, shadow, sf);
-        return;
-    }
     if (wv >= M) return;
     wide_latent<RT, DOT, FUSE>(packed, seg_begin, rows, W, gW, gbias, slab, row_shift, kdiv, E, D, wv, slice, lane, lr,
                                shadow, sf);
 }
 
-template <typename RT, bool DOT, bool FUSE>
-__device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, const int* __restrict__ seg_begin,
-                                            const RT* __restrict__ rows, const float* __restrict__ W,
-                                            float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
-                                            const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
-                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow, SfArgs sf) {
+// The accumulation of entries [beg, end) of latent j over one 256-column slice: acc += c * row piece in
+// entry order, bsum += c, and (DOT) the slice's partial dot of every entry into slab[slice][position].
+template <typename RT, bool DOT>
+__device__ __forceinline__ void wide_accumulate(const uint2* __restrict__ packed, const RT* __restrict__ rows,
+                                                const float* __restrict__ W, float* __restrict__ slab, FastDiv kdiv,
+                                                int64_t E, int D, int j, int beg, int end, int slice, int lane,
+                                                float4& acc, float& bsum) {
     const int col = slice * 256 + lane * 4;
-    const int beg = seg_begin[j], end = seg_begin[j + 1];
     // W and gW are streamed once: non-temporal, so that they do not displace the resident slice of `rows`
     typedef float f4 __attribute__((ext_vector_type(4)));
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -678,8 +693,6 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
         const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(W + (int64_t)j * D + col));
         w = make_float4(t[0], t[1], t[2], t[3]);
     }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float bsum = 0.f;
     const RT* rcol = rows + col;
     float* sl = slab + (int64_t)slice * E;
 
@@ -741,6 +754,19 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
         const int u = lane >> 3;
         if ((lane & 7) == 0 && p + u < end) sl[p + u] = d[0];
     }
+}
+
+template <typename RT, bool DOT, bool FUSE>
+__device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, const int* __restrict__ seg_begin,
+                                            const RT* __restrict__ rows, const float* __restrict__ W,
+                                            float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ slab,
+                                            const float* __restrict__ row_shift, FastDiv kdiv, int64_t E, int D, int j,
+                                            int slice, int lane, float lr, bf16_t* __restrict__ shadow, SfArgs sf) {
+    const int col = slice * 256 + lane * 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    wide_accumulate<RT, DOT>(packed, rows, W, slab, kdiv, E, D, j, seg_begin[j], seg_begin[j + 1], slice, lane, acc, bsum);
     if (row_shift != nullptr) {
         const float4 sh = *reinterpret_cast<const float4*>(row_shift + col);
         acc.x = fmaf(-bsum, sh.x, acc.x);
@@ -776,14 +802,222 @@ __device__ __forceinline__ void wide_latent(const uint2* __restrict__ packed, co
     if (gbias != nullptr && slice == 0 && lane == 0) gbias[j] = bsum;
 }
 
-// latents whose segment is longer than T: out[0] = their number (zeroed before the launch),
-// out[1..] = the latents, in arrival order (the order only decides which wave takes which)
+// ---------------------------------------------------------------------------------------
+// Long segments (dense latents). The L2-sliced kernel gives a latent to one 8-lane group, so a
+// workgroup lives as long as its longest segment; a wave-per-latent kernel is no better: one wave walks
+// the segment 8 entries at a time, and with a latent that fires on 40 % of 16384 tokens that single
+// chain of ~800 round trips (1.8 - 2.3 ms) was the whole launch. Latents with more than SKEW_T entries
+// are therefore listed on the device (no host round trip; the list is usually empty), their segments
+// cut into chunks of LONG_CH entries, every chunk reduced by a lane group of its own into a partial row
+// (seg_long_chunk_kernel, entry order inside the chunk), and the partial rows of a latent
+// added up in chunk order by seg_long_combine_kernel, which writes the gradient row or applies the fused
+// optimizer step. The order of the sum is fixed by the segment alone (chunks of LONG_CH in entry order,
+// then the chunks in order): the same bits on every run, but not the bits of one sequential chain over
+// the whole segment, which is what the other kernel forms compute.
+// hdr[0] = number of long latents, hdr[1] = number of chunks (both zeroed before the launch);
+// list[i] = {latent, first chunk}, ctab[chunk] = {latent, chunk inside the latent}. Which slot a latent
+// gets is arrival order: it decides where its partial rows lie, not what they hold.
+#ifndef SPHIP_LONG_CH
+#define SPHIP_LONG_CH 128
+#endif
+constexpr int LONG_CH = SPHIP_LONG_CH;
 __global__ __launch_bounds__(256) void seg_long_list_kernel(const int* __restrict__ seg_begin, int M, int T, int cap,
-                                                            int* __restrict__ out) {
+                                                            int chunk_cap, int* __restrict__ hdr,
+                                                            int2* __restrict__ list, int2* __restrict__ ctab) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= M || seg_begin[j + 1] - seg_begin[j] <= T) return;
-    const int pos = atomicAdd(out, 1);
-    if (pos < cap) out[1 + pos] = j;
+    if (j >= M) return;
+    const int len = seg_begin[j + 1] - seg_begin[j];
+    if (len <= T) return;
+    const int nch = (len + LONG_CH - 1) / LONG_CH;
+    const int pos = atomicAdd(hdr, 1);
+    const int cb = atomicAdd(hdr + 1, nch);
+    if (pos >= cap || cb + nch > chunk_cap) return;          // cannot happen: cap >= E / T, chunk_cap >= E / CH + E / T
+    list[pos] = make_int2(j, cb);
+    for (int c = 0; c < nch; ++c) ctab[cb + c] = make_int2(j, c);
+}
+
+// One workgroup reduces 32 chunks over one 128-byte column slice, eight lanes per chunk, from the
+// slice-major copy of the rows like seg_wgrad_sliced_kernel (the N x 128 B slice stays in the XCD's L2);
+// the chunks are equally long, so the lane groups finish together. Fixed grid: the workgroups of an XCD
+// walk (slice, block of chunks) items slice after slice. DOT: the slice's partial dot of every entry
+// goes to slab[slice][position], the layout of the L2-sliced kernel (whose parked ranges may have left
+// garbage at these positions: this kernel runs after it on the same stream).
+template <typename RT, bool DOT, bool PK4>
+__global__ __launch_bounds__(256) void seg_long_chunk_kernel(const void* __restrict__ plist_,
+                                                             const int* __restrict__ seg_begin,
+                                                             const RT* __restrict__ rows_sm,
+                                                             const float* __restrict__ Wdot, float* __restrict__ slab,
+                                                             FastDiv kdiv, int64_t N, int64_t E, int D, int num_slices,
+                                                             const int* __restrict__ hdr, const int2* __restrict__ ctab,
+                                                             int chunk_cap, float* __restrict__ prow,
+                                                             float* __restrict__ pbsum) {
+    constexpr int C = Piece<RT>::COLS;
+    constexpr int SLICE_COLS = 8 * C;
+    constexpr int U = 8;
+    typedef typename std::conditional<PK4, unsigned, uint2>::type Entry;
+    typedef typename Piece<RT>::Raw Raw;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ Entry sh_pk[32 * LONG_CH];
+    const Entry* plist = reinterpret_cast<const Entry*>(plist_);
+    const int n_chunks = min(hdr[1], chunk_cap);
+    const int n_blocks = (n_chunks + 31) >> 5;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, G = gridDim.x >> 3;
+    const int rounds = (num_slices + 7) >> 3;
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    Entry* my = sh_pk + g * LONG_CH;
+    for (int item = local; item < rounds * n_blocks; item += G) {      // block-uniform
+        const int slice = xcd + 8 * (item / n_blocks);
+        if (slice >= num_slices) break;
+        const int w = (item % n_blocks) * 32 + g;
+        int j = 0, beg = 0, len = 0;
+        if (w < n_chunks) {
+            const int2 t = ctab[w];
+            j = t.x;
+            beg = seg_begin[j] + t.y * LONG_CH;
+            len = min(seg_begin[j + 1] - beg, LONG_CH);
+        }
+        const int col = slice * SLICE_COLS + sub * C;
+        const bool live = w < n_chunks && col < D;
+        __syncthreads();                                                 // the previous item's slots are done with
+        for (int i = sub; i < len; i += 8) my[i] = plist[beg + i];
+        float wdot[DOT ? C : 1];
+        if (DOT) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) wdot[c] = 0.f;
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < C; c += 4) {
+                    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(Wdot + (int64_t)j * D + col + c));
+                    wdot[c] = t[0], wdot[c + 1] = t[1], wdot[c + 2] = t[2], wdot[c + 3] = t[3];
+                }
+            }
+        }
+        __syncthreads();
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        float bsum = 0.f;
+        const RT* base = rows_sm + ((int64_t)slice * N * 8 + sub) * C;
+        const int n = live ? len : 0;
+        for (int p = 0; p < n; p += U) {
+            Entry pk[U];
+            Raw v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pk[u] = my[min(p + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                unsigned tok;
+                if constexpr (PK4) tok = pk[u] >> 16;
+                else tok = fastdiv(pk[u].x, kdiv);
+                v[u] = Piece<RT>::load(base + (int64_t)tok * (8 * C));
+            }
+            if (DOT) {
+                float mine_d = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) d = fmaf(Piece<RT>::get(v[u], c), wdot[c], d);
+                    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xF, 0xF, true));
+                    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xF, 0xF, true));
+                    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true));
+                    mine_d = (sub == u) ? d : mine_d;
+                }
+                // parked in the slot of the entry itself (it is in registers by now)
+                if (p + sub < n) {
+                    if constexpr (PK4) my[p + sub] = __float_as_uint(mine_d);
+                    else my[p + sub].x = __float_as_uint(mine_d);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (p + u < n) {                        // group-uniform; keeps the sequential fma chain exact
+                    float cf;
+                    if constexpr (PK4) cf = __uint_as_float(pk[u] << 16);
+                    else cf = __uint_as_float(pk[u].y);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(cf, Piece<RT>::get(v[u], c), acc[c]);
+                    bsum += cf;
+                }
+            }
+        }
+        if (DOT) {
+            __syncthreads();
+            float* sl = slab + (int64_t)slice * E + beg;
+            for (int i = sub; i < n; i += 8) {
+                float d;
+                if constexpr (PK4) d = __uint_as_float(my[i]);
+                else d = __uint_as_float(my[i].x);
+                sl[i] = d;
+            }
+        }
+        if (live) {
+            float* o = prow + (int64_t)w * D + col;
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                const f4 t = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o + c));
+            }
+            if (slice == 0 && sub == 0) pbsum[w] = bsum;
+        }
+    }
+}
+
+// gW[j, :] (or, FUSE, the optimizer step of parameter row j) from the partial rows of latent j's chunks
+template <bool FUSE>
+__global__ __launch_bounds__(256) void seg_long_combine_kernel(const int* __restrict__ hdr, const int2* __restrict__ list,
+                                                               int cap, const int* __restrict__ seg_begin,
+                                                               const float* __restrict__ prow,
+                                                               const float* __restrict__ pbsum,
+                                                               const float* __restrict__ row_shift,
+                                                               float* __restrict__ gW, int D, float lr,
+                                                               bf16_t* __restrict__ shadow, SfArgs sf) {
+    const int n_long = min(hdr[0], cap);
+    for (int i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const int2 t = list[i];
+        const int j = t.x, cb = t.y;
+        const int nch = (seg_begin[j + 1] - seg_begin[j] + LONG_CH - 1) / LONG_CH;
+        float bsum = pbsum[cb];
+        for (int c = 1; c < nch; ++c) bsum += pbsum[cb + c];
+        for (int col = threadIdx.x * 4; col < D; col += 1024) {
+            float4 acc = *reinterpret_cast<const float4*>(prow + (int64_t)cb * D + col);
+            for (int c = 1; c < nch; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(prow + (int64_t)(cb + c) * D + col);
+                acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+            }
+            if (row_shift != nullptr) {
+                const float4 sh = *reinterpret_cast<const float4*>(row_shift + col);
+                acc.x = fmaf(-bsum, sh.x, acc.x);
+                acc.y = fmaf(-bsum, sh.y, acc.y);
+                acc.z = fmaf(-bsum, sh.z, acc.z);
+                acc.w = fmaf(-bsum, sh.w, acc.w);
+            }
+            if (FUSE) {       // gW is the parameter: SignSGD / schedule-free step in place (see seg_wgrad_sliced_kernel)
+                float4 p4 = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col);
+                if (sf.z != nullptr) {
+                    float4 z4 = *reinterpret_cast<const float4*>(sf.z + (int64_t)j * D + col);
+                    sf_update(p4.x, z4.x, (float)((acc.x > 0.f) - (acc.x < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+                    sf_update(p4.y, z4.y, (float)((acc.y > 0.f) - (acc.y < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+                    sf_update(p4.z, z4.z, (float)((acc.z > 0.f) - (acc.z < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+                    sf_update(p4.w, z4.w, (float)((acc.w > 0.f) - (acc.w < 0.f)), lr, sf.w_undo, sf.c, sf.w_y);
+                    *reinterpret_cast<float4*>(sf.z + (int64_t)j * D + col) = z4;
+                } else {
+                    p4.x -= lr * (float)((acc.x > 0.f) - (acc.x < 0.f));
+                    p4.y -= lr * (float)((acc.y > 0.f) - (acc.y < 0.f));
+                    p4.z -= lr * (float)((acc.z > 0.f) - (acc.z < 0.f));
+                    p4.w -= lr * (float)((acc.w > 0.f) - (acc.w < 0.f));
+                }
+                *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = p4;
+                if (shadow != nullptr) {
+                    const unsigned lo = (unsigned)f32_to_bf16(p4.x) | ((unsigned)f32_to_bf16(p4.y) << 16);
+                    const unsigned hi = (unsigned)f32_to_bf16(p4.z) | ((unsigned)f32_to_bf16(p4.w) << 16);
+                    *reinterpret_cast<uint2*>(shadow + (int64_t)j * D + col) = make_uint2(lo, hi);
+                }
+            } else {
+                *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
+            }
+        }
+    }
 }
 
 // dcoeff[entry at position p] = sum over slices of slab[slice][p], slices in ascending order
@@ -806,47 +1040,22 @@ __global__ __launch_bounds__(256) void seg_dcoeff_bounded_kernel(const uint2* __
     dcoeff[packed[p].x] = t;
 }
 
-// The same sum when latents with more than T entries took the wide kernel (nB slices of 256
-// columns in slabB) and all others the L2-sliced one (nA slices of 32 columns in slabA): the
-// latent of position p is found by bisection of seg_begin.
-__global__ __launch_bounds__(256) void seg_dcoeff_mixed_kernel(const uint2* __restrict__ packed,
-                                                               const float* __restrict__ slabA, int nA,
-                                                               const float* __restrict__ slabB, int nB, int64_t E,
-                                                               const int* __restrict__ seg_begin, int M, int T,
-                                                               float* __restrict__ dcoeff) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= seg_begin[M]) return;
-    int lo = 0, hi = M;                       // invariant: seg_begin[lo] <= p < seg_begin[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_begin[mid] <= p) lo = mid; else hi = mid;
-    }
-    const bool is_long = seg_begin[lo + 1] - seg_begin[lo] > T;
-    const float* slab = is_long ? slabB : slabA;
-    const int n = is_long ? nB : nA;
-    float t = 0.f;
-    int sidx = 0;
-    for (; sidx + 16 <= n; sidx += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(slab + (int64_t)(sidx + u) * E + p);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t += v[u];
-    }
-    for (; sidx < n; ++sidx) t += slab[(int64_t)sidx * E + p];
-    dcoeff[packed[p].x] = t;
-}
-
-// segments longer than this go from the L2-sliced kernel to the wide kernel, whose waves (a small
-// fixed grid of LONG_GRID workgroups per column slice) walk the list of such latents
-constexpr int SKEW_T = 512;
+// segments longer than this go from the L2-sliced kernel to the chunked long-segment kernels, whose
+// workgroups (a fixed grid of LONG_GRID) walk the chunks of such latents
+#ifndef SPHIP_SKEW_T
+#define SPHIP_SKEW_T 128
+#endif
+constexpr int SKEW_T = SPHIP_SKEW_T;
 // without dots the wide (wave-per-latent) kernel takes over from the L2-sliced one when the mean segment
 // is this long (AuxK as row gathers: ~2500 entries on each dead latent); the multi-top-k decode
 // (mean 4 N k / M = 96 at the headline shape) stays with the L2-sliced kernel: 20.7 -> see DESIGN
 #ifndef SPHIP_WIDE_MEAN
 #define SPHIP_WIDE_MEAN 256
 #endif
-constexpr unsigned LONG_GRID = 256;
+#ifndef SPHIP_LONG_GRID
+#define SPHIP_LONG_GRID 1024
+#endif
+constexpr unsigned LONG_GRID = SPHIP_LONG_GRID;      // a multiple of 8: the workgroups of an XCD share slices
 
 template <typename RT, bool FUSE = false, bool DOT = false>
 static bool launch_sliced(const uint2* packed, const int* seg, const void* rows, void* rows_sm, float* gW,
@@ -920,19 +1129,71 @@ static bool l2dot_eligible(int64_t N, int64_t k, int64_t D) {
     return D % 32 == 0 && D >= 512 && (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) <= ((size_t)8 << 30);
 }
 static size_t l2dot_bytes(int64_t N, int64_t k, int64_t D) {
-    // slice-major rows + 128-byte-slice partials + the wide kernel's partials for long latents
+    // slice-major rows + 128-byte-slice partials
     return l2dot_eligible(N, k, D) ? ((rows_sm_bytes(N, D) + 255) & ~(size_t)255) +
-                                         (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float) + slab_bytes(N, k, D)
+                                         (size_t)(D / 32) * (size_t)N * (size_t)k * sizeof(float)
                                    : 0;
 }
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
-static size_t long_list_bytes(int64_t N, int64_t k) {
-    return (((size_t)(N * k / sphip::SKEW_T + 2) * sizeof(int)) + 255) & ~(size_t)255;
+// The long-segment path's tail of the workspace (seg_long_* kernels): header, list of long latents
+// (at most E / SKEW_T), chunk table and per-chunk coefficient sums (at most E / LONG_CH + E / SKEW_T
+// chunks), then one partial row of D floats per chunk.
+struct LongTail {
+    int* hdr;
+    int2* list;
+    int2* ctab;
+    float* pbsum;
+    float* prow;
+    int cap, chunk_cap;
+};
+static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+static int long_cap(int64_t N, int64_t k) { return (int)(N * k / sphip::SKEW_T + 2); }
+static int long_chunk_cap(int64_t N, int64_t k) { return (int)(N * k / sphip::LONG_CH + N * k / sphip::SKEW_T + 2); }
+static size_t long_tail_bytes(int64_t N, int64_t k, int64_t D) {
+    if (!wide_eligible(D)) return 0;
+    const size_t cap = (size_t)long_cap(N, k), cc = (size_t)long_chunk_cap(N, k);
+    return 256 + up256(cap * sizeof(int2)) + up256(cc * sizeof(int2)) + up256(cc * sizeof(float)) +
+           up256(cc * (size_t)D * sizeof(float));
 }
-// the list of long latents sits at the end of the workspace
-static int* skew_word(void* workspace, int64_t N, int64_t k, int64_t D) {
-    return (int*)((char*)workspace + sphip_weight_grad_workspace_bytes(N, k, D) - long_list_bytes(N, k));
+// the tail sits at the end of the workspace
+static LongTail long_tail(void* workspace, int64_t N, int64_t k, int64_t D) {
+    char* p = (char*)workspace + sphip_weight_grad_workspace_bytes(N, k, D) - long_tail_bytes(N, k, D);
+    LongTail t;
+    t.cap = long_cap(N, k), t.chunk_cap = long_chunk_cap(N, k);
+    t.hdr = (int*)p, p += 256;
+    t.list = (int2*)p, p += up256((size_t)t.cap * sizeof(int2));
+    t.ctab = (int2*)p, p += up256((size_t)t.chunk_cap * sizeof(int2));
+    t.pbsum = (float*)p, p += up256((size_t)t.chunk_cap * sizeof(float));
+    t.prow = (float*)p;
+    return t;
+}
+// lists the long latents: returns false if the launch could not be enqueued
+static bool list_long_latents(const LongTail& t, const int* seg_begin, int64_t M, hipStream_t s) {
+    if (hipMemsetAsync(t.hdr, 0, 2 * sizeof(int), s) != hipSuccess) return false;
+    hipLaunchKernelGGL(sphip::seg_long_list_kernel, dim3((unsigned)sphip::cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M,
+                       sphip::SKEW_T, t.cap, t.chunk_cap, t.hdr, t.list, t.ctab);
+    return true;
+}
+// the chunk partials of the listed latents (rows_sm: the slice-major copy launch_sliced has made), then
+// their combination into gW rows (FUSE: the optimizer step)
+template <typename RT, bool DOT, bool FUSE>
+static void reduce_long_latents(const LongTail& t, const uint2* packed, const unsigned* packed4, const int* seg_begin,
+                                const void* rows_sm, const float* W, float* gW, float* slab, const float* row_shift,
+                                int64_t N, int64_t k, int64_t D, hipStream_t s, float lr = 0.f,
+                                sphip::bf16_t* shadow = nullptr, sphip::SfArgs sf = sphip::SfArgs{nullptr, 0.f, 0.f, 0.f}) {
+    using namespace sphip;
+    const int num_slices = (int)cdiv(D, 8 * Piece<RT>::COLS);
+    const FastDiv kd = make_fastdiv((unsigned)k);
+    dim3 grid(LONG_GRID), block(256);
+    if (packed4 != nullptr)
+        hipLaunchKernelGGL((seg_long_chunk_kernel<RT, DOT, true>), grid, block, 0, s, (const void*)packed4, seg_begin,
+                           (const RT*)rows_sm, W, slab, kd, N, N * k, (int)D, num_slices, t.hdr, t.ctab, t.chunk_cap, t.prow, t.pbsum);
+    else
+        hipLaunchKernelGGL((seg_long_chunk_kernel<RT, DOT, false>), grid, block, 0, s, (const void*)packed, seg_begin,
+                           (const RT*)rows_sm, W, slab, kd, N, N * k, (int)D, num_slices, t.hdr, t.ctab, t.chunk_cap, t.prow, t.pbsum);
+    hipLaunchKernelGGL((seg_long_combine_kernel<FUSE>), dim3(256), block, 0, s, t.hdr, t.list, t.cap, seg_begin, t.prow,
+                       t.pbsum, row_shift, gW, (int)D, lr, shadow, sf);
 }
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
@@ -942,15 +1203,45 @@ extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_
     const size_t b = slab_bytes(N, k, D), c = l2dot_bytes(N, k, D);
     a = a > b ? a : b;
     a = a > c ? a : c;
-    // + the list of long latents (at most N k / SKEW_T of them, preceded by their count)
-    return packed_bytes(N, k) + ((a + 255) & ~(size_t)255) + long_list_bytes(N, k);
+    // + the long-segment path's lists and partial rows
+    return packed_bytes(N, k) + ((a + 255) & ~(size_t)255) + long_tail_bytes(N, k, D);
 }
+
+static int launch_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype, int64_t M,
+                             float* out, hipStream_t s) {
+    using namespace sphip;
+    dim3 grid((unsigned)cdiv(M, 256)), block(256);
+    if (coeff_dtype == SPHIP_F32)
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<float>), grid, block, 0, s, perm, seg_begin, (const float*)coeff, (int)M, out);
+    else
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<bf16_t>), grid, block, 0, s, perm, seg_begin, (const bf16_t*)coeff, (int)M, out);
+    SPHIP_CHECK_LAUNCH("segment_coeff_sums");
+    return SPHIP_OK;
+}
+
+static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
+                            float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
+                            int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                                            float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
                                            int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
                                            void* stream) {
+    // the bias gradient comes from seg_coeff_sum_kernel whatever form computes the weight gradient
+    const int rc = weight_grad_impl(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, W, gW, nullptr, dcoeff, row_shift,
+                                    N, k, M, D, workspace, workspace_bytes, stream);
+    if (rc != SPHIP_OK || gbias == nullptr) return rc;
+    return launch_coeff_sums(perm, seg_begin, coeff, coeff_dtype, M, gbias, (hipStream_t)stream);
+}
+
+static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
+                            float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
+                            int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
+                            void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && gW, SPHIP_EINVAL, "segmented_weight_grad: null pointer");
@@ -991,29 +1282,24 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     if (dot && rows_dtype == SPHIP_F32 && l2dot_eligible(N, k, D) && D / 32 <= 65535 &&
         ((force && force[0] == 'l') || (!force && big && N * k >= 4 * M && N * 128 <= (3ll << 20)))) {
         float* slab = (float*)((char*)rows_sm + ((rows_sm_bytes(N, D) + 255) & ~(size_t)255));
-        float* slab_long = slab + (size_t)(D / 32) * (size_t)E;
         // latents with more than SKEW_T entries (dense latents: a workgroup of the sliced kernel
         // lives as long as its longest segment) are listed on the device and left to the
         // wave-per-latent wide kernel, launched next to the sliced one with a small fixed grid
-        int* skew = wide_eligible(D) ? skew_word(workspace, N, k, D) : nullptr;
-        if (skew != nullptr) {
-            SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
-            hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
-        }
+        // latents with more than SKEW_T entries (dense latents: a workgroup of the sliced kernel
+        // lives as long as its longest segment) are listed on the device and left to the chunked
+        // long-segment kernels, launched next to the sliced one with small fixed grids
+        const bool use_long = wide_eligible(D);
+        const LongTail lt = use_long ? long_tail(workspace, N, k, D) : LongTail{};
+        const int* skew = use_long ? lt.hdr : nullptr;
+        if (use_long)
+            SPHIP_REQUIRE(list_long_latents(lt, seg_begin, M, s), SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
         if (launch_sliced<float, false, true>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M,
                                               (int)D, s, 0.f, nullptr, skew, W, slab, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr,
                                               nullptr, packed4)) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(l2 dot)");
-            if (skew != nullptr) {
-                // (four column slices per launch, to keep the list's working set inside the
-                // Infinity Cache, measured slower: 32 against 26 ms on the collapsed 262144-latent
-                // transcoder run; the list's waves are latency-bound, not bandwidth-bound)
-                dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
-                hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, true, false, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, slab_long, row_shift, make_fastdiv((unsigned)k), E, (int)M, (int)D, skew, SKEW_T);
-                hipLaunchKernelGGL(seg_dcoeff_mixed_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, (int)(D / 32), slab_long, (int)(D / 256), E, seg_begin, (int)M, SKEW_T, dcoeff);
-            } else {
-                hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
-            }
+            if (use_long)
+                reduce_long_latents<float, true, false>(lt, packed, packed4, seg_begin, rows_sm, W, gW, slab, row_shift, N, k, D, s);
+            hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
             return SPHIP_OK;
         }
@@ -1040,22 +1326,20 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     if (!dot && !(force && (force[0] == 'f' || force[0] == 'w'))) {
         // the L2-sliced kernel, and next to it the wide kernel: a device-side word (the longest
         // segment) decides which of the two launches does the work, without a host round trip
-        int* skew = (wide_eligible(D) && big && !force) ? skew_word(workspace, N, k, D) : nullptr;
-        if (skew != nullptr) {
-            SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
-            hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
-        }
+        const bool use_long = wide_eligible(D) && big && !force;
+        const LongTail lt = use_long ? long_tail(workspace, N, k, D) : LongTail{};
+        const int* skew = use_long ? lt.hdr : nullptr;
+        if (use_long)
+            SPHIP_REQUIRE(list_long_latents(lt, seg_begin, M, s), SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
         const bool done = rows_dtype == SPHIP_F32
                               ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4)
                               : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4);
         if (done) {
-            if (skew != nullptr) {
-                const FastDiv kd = make_fastdiv((unsigned)k);
-                dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
+            if (use_long) {
                 if (rows_dtype == SPHIP_F32)
-                    hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, false, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, W, gW, gbias, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T);
+                    reduce_long_latents<float, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s);
                 else
-                    hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, false, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, W, gW, gbias, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T);
+                    reduce_long_latents<bf16_t, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s);
             }
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
@@ -1078,13 +1362,7 @@ extern "C" int sphip_segment_coeff_sums(const uint32_t* perm, const int32_t* seg
     SPHIP_REQUIRE(valid_dtype(coeff_dtype), SPHIP_EINVAL, "segment_coeff_sums: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && out, SPHIP_EINVAL, "segment_coeff_sums: null pointer");
     SPHIP_REQUIRE(M > 0 && M < (1ll << 31) - 256, SPHIP_EINVAL, "segment_coeff_sums: bad M");
-    dim3 grid((unsigned)cdiv(M, 256)), block(256);
-    if (coeff_dtype == SPHIP_F32)
-        hipLaunchKernelGGL((seg_coeff_sum_kernel<float>), grid, block, 0, (hipStream_t)stream, perm, seg_begin, (const float*)coeff, (int)M, out);
-    else
-        hipLaunchKernelGGL((seg_coeff_sum_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, perm, seg_begin, (const bf16_t*)coeff, (int)M, out);
-    SPHIP_CHECK_LAUNCH("segment_coeff_sums");
-    return SPHIP_OK;
+    return launch_coeff_sums(perm, seg_begin, coeff, coeff_dtype, M, out, (hipStream_t)stream);
 }
 
 static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype,
@@ -1122,22 +1400,21 @@ static int fused_weight_grad_step(const uint32_t* perm, const int32_t* seg_begin
     else
         hipLaunchKernelGGL((seg_pack_kernel<bf16_t>), dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, perm, (const bf16_t*)coeff, E, seg_begin, (int)M, packed, (float*)nullptr, packed4, make_fastdiv((unsigned)k));
     const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
-    int* skew = (wide_eligible(D) && big) ? skew_word(workspace, N, k, D) : nullptr;
-    if (skew != nullptr) {
-        SPHIP_REQUIRE(hipMemsetAsync(skew, 0, sizeof(int), s) == hipSuccess, SPHIP_ELAUNCH, "segmented_weight_grad_signsgd: memset failed");
-        hipLaunchKernelGGL(seg_long_list_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, seg_begin, (int)M, SKEW_T, (int)(E / SKEW_T + 1), skew);
-    }
+    const bool use_long = wide_eligible(D) && big;
+    const LongTail lt = use_long ? long_tail(workspace, N, k, D) : LongTail{};
+    const int* skew = use_long ? lt.hdr : nullptr;
+    if (use_long)
+        SPHIP_REQUIRE(list_long_latents(lt, seg_begin, M, s), SPHIP_ELAUNCH, "segmented_weight_grad_signsgd: memset failed");
     const bool done = rows_dtype == SPHIP_F32
                           ? launch_sliced<float, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials, packed4)
                           : launch_sliced<bf16_t, true>(packed, seg_begin, rows, rows_sm, param, nullptr, row_shift, N, (int)k, (int)M, (int)D, s, lr, (bf16_t*)bf16_shadow, skew, nullptr, nullptr, sf, coeff_sums, bdec_partials, packed4);
     SPHIP_REQUIRE(done, SPHIP_EUNSUPPORTED, "segmented_weight_grad_signsgd: shape not supported by the sliced kernel");
-    if (skew != nullptr) {
-        const FastDiv kd = make_fastdiv((unsigned)k);
-        dim3 grid(LONG_GRID, (unsigned)(D / 256)), block(256);
+    if (use_long) {
+        // (after the sliced kernel: its gb^T W partials read the old rows of the long latents too)
         if (rows_dtype == SPHIP_F32)
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<float, false, true, true>), grid, block, 0, s, packed, seg_begin, (const float*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow, 0, sf);
+            reduce_long_latents<float, false, true>(lt, packed, packed4, seg_begin, rows_sm, nullptr, param, nullptr, row_shift, N, k, D, s, lr, (bf16_t*)bf16_shadow, sf);
         else
-            hipLaunchKernelGGL((seg_wgrad_wide_kernel<bf16_t, false, true, true>), grid, block, 0, s, packed, seg_begin, (const bf16_t*)rows, (const float*)nullptr, param, (float*)nullptr, (float*)nullptr, row_shift, kd, E, (int)M, (int)D, skew, SKEW_T, lr, (bf16_t*)bf16_shadow, 0, sf);
+            reduce_long_latents<bf16_t, false, true>(lt, packed, packed4, seg_begin, rows_sm, nullptr, param, nullptr, row_shift, N, k, D, s, lr, (bf16_t*)bf16_shadow, sf);
     }
     SPHIP_CHECK_LAUNCH("segmented_weight_grad_signsgd");
     return SPHIP_OK;

@@ -692,10 +692,12 @@ def test_scatter_rows_and_scatter_add_rows(device, R, D, M):
 @pytest.mark.parametrize("skewed", [False, True])
 @pytest.mark.parametrize("rdtype", [torch.bfloat16, torch.float32])
 def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, skewed, rdtype):
-    """Without a dot part the L2-sliced kernel leaves latents with long segments (dense latents) to
-    the wave-per-latent wide kernel, launched next to it over a device-side list of them. Either
-    way the gradient equals the full-row kernel's bit for bit, and the fused SignSGD form
-    (sphip_segmented_weight_grad_signsgd) equals gradient + separate step."""
+    """Without a dot part the L2-sliced kernel leaves latents with long segments (dense latents,
+    more than 512 entries) to the chunked long-segment kernels, launched next to it over a device-side
+    list of them: 256-entry chunks summed in entry order, chunk partials added in order. The rows of
+    all other latents equal the full-row kernel's bit for bit; a long latent's row equals it to fp32
+    summation-order accuracy and is the same on every run; the fused SignSGD form
+    (sphip_segmented_weight_grad_signsgd) equals gradient + separate step bit for bit."""
     from sparsify_amd import ops
     torch.manual_seed(5)
     N, D, M, k, lr = 4096, 1024, 4096, 32, 3e-3          # N * D * 2 B = 8 MiB: the training-size dispatch
@@ -712,7 +714,18 @@ def test_weight_grad_long_segments_take_the_wide_kernel(device, monkeypatch, ske
     monkeypatch.setenv("SPHIP_WGRAD", "full")
     gW_full, gb_full, _ = ops.segmented_weight_grad(seg, coeff, rows, want_bias=True, row_shift=shift)
     monkeypatch.delenv("SPHIP_WGRAD")
-    assert torch.equal(gW, gW_full) and torch.equal(gb, gb_full)
+    long_rows = torch.zeros(M, dtype=torch.bool, device="cuda")
+    if skewed:
+        long_rows[torch.tensor([7, 1000, 4095])] = True
+    assert torch.equal(gW[~long_rows], gW_full[~long_rows]) and torch.equal(gb, gb_full)
+    if skewed:
+        # 4096 terms of magnitude ~1: the two summation orders differ by a few ulp of the partial sums
+        torch.testing.assert_close(gW[long_rows], gW_full[long_rows], rtol=1e-5, atol=1e-3)
+        c7 = (coeff.double() * (idx == 7)).sum(1)
+        ref64 = (c7[:, None] * rows.double()).sum(0) - c7.sum() * shift.double()
+        assert (gW[7].double() - ref64).abs().max() <= 2 * (gW_full[7].double() - ref64).abs().max() + 1e-4
+        gW_again, _, _ = ops.segmented_weight_grad(seg, coeff, rows, want_bias=True, row_shift=shift)
+        assert torch.equal(gW, gW_again)
     # fused with the optimizer step
     p0 = dev(torch.randn(M, D))
     sep, fused = p0.clone(), p0.clone()
@@ -774,9 +787,9 @@ def test_fused_weight_grad_step_ragged_shapes(device, N, D, M, k, rdtype, sfree)
 @pytest.mark.parametrize("skewed", [False, True])
 def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
     """W_dec gradient + d top_acts through the L2-sliced kernel with per-slice dot partials
-    (SPHIP_WGRAD=l2; long segments go to the wide kernel over the device-side list, and the sum of
-    the partials picks the right slab per entry): gW bit for bit the full-row kernel's, the dots
-    equal up to summation order."""
+    (SPHIP_WGRAD=l2; long segments go to the chunked long-segment kernels over the device-side list,
+    and the sum of the partials picks the right slab per entry): gW bit for bit the full-row kernel's
+    (long latents: to summation-order accuracy), the dots equal up to summation order."""
     from sparsify_amd import ops
     torch.manual_seed(11)
     N, D, M, k = 4096, 1024, 4096, 32
@@ -793,7 +806,11 @@ def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
     assert torch.equal(gW, gW2) and torch.equal(dc, dc2)                      # deterministic
     monkeypatch.setenv("SPHIP_WGRAD", "full")
     gW_f, gb_f, dc_f = ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True)
-    assert torch.equal(gW, gW_f) and torch.equal(gb, gb_f)
+    long_rows = torch.zeros(M, dtype=torch.bool, device="cuda")
+    if skewed:
+        long_rows[torch.tensor([5, 4090, 17])] = True    # chunked sums: fp32 summation-order accuracy (see above)
+        torch.testing.assert_close(gW[long_rows], gW_f[long_rows], rtol=1e-5, atol=1e-3)
+    assert torch.equal(gW[~long_rows], gW_f[~long_rows]) and torch.equal(gb, gb_f)
     ref = (rows[:, None, :] * W[idx]).sum(-1) if N * k * D <= (1 << 28) else None
     torch.testing.assert_close(dc, dc_f, rtol=1e-4, atol=1e-3)
     if ref is not None:
