@@ -162,11 +162,16 @@ def main():
     if os.environ.get("SPHIP_HANG_DUMP"):      # debugging aid: dump all stacks if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SPHIP_HANG_DUMP"]), exit=True)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: one child process per GPU, started before anything here
+        # touches the GPU (the reference's entry point takes its rank from LOCAL_RANK the same way,
+        # sparsify/__main__.py:144-155); under torch.distributed.run the environment is already there
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -365,6 +370,33 @@ def variant_run(kind: str, N, D, M, k, device, steps: int = 4, warm: int = 2) ->
     del tr, batches, src
     torch.cuda.empty_cache()
     return out
+
+
+def spawn_ranks(n: int) -> int:
+    """Runs this script once per rank as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1) and returns the largest exit code; rank 0's JSON line goes to this
+    process's stdout. The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    try:
+        while any(pr.poll() is None for pr in procs):
+            if any(pr.poll() not in (None, 0) for pr in procs):
+                break                         # a rank that failed leaves the others waiting in a collective
+            time.sleep(0.2)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    return max(abs(pr.returncode) for pr in procs)
 
 
 def _fp32_forward(fwd, self, *a, **kw):
