@@ -20,7 +20,8 @@ How the step is laid out here (none of this structure is the reference's):
 * Data parallel (``ddp=True`` under torch.distributed): the reference deals whole parameters to
   ranks round-robin and all-gathers their bf16 updates (muon.py:143-181), which leaves all but two
   ranks idle when a coder has two big matrices. Here the rows of a tall iterate are split over
-  the ranks instead: every rank keeps 1/W of the momentum buffer, runs the products on its rows,
+  the ranks instead: every rank keeps 1/W of the momentum buffer (gathered into the reference's
+  whole-parameter ``exp_avg`` on save, cut back on load), runs the products on its rows,
   the short x short Gram matrix is summed over ranks in fp32 (one all-reduce of S x S per
   Newton-Schulz step, RCCL), and the bf16 update rows are all-gathered once at the end -- the same
   bytes on the wire as the reference's all-gather, 1/W of the FLOPs per rank for every matrix.
@@ -100,6 +101,57 @@ class Muon(torch.optim.Optimizer):
             return parallel.rank() * per, (parallel.rank() + 1) * per, True
         return 0, R, False
 
+    # ---- optimizer state in the reference's format: state["exp_avg"] with the parameter's whole shape
+    # (muon.py:154-157; rank 0 writes optimizer_{i}.pt, trainer.py:663-668). Between steps a
+    # row-sharded rank holds its rows only, so state_dict() is a collective there (every rank calls
+    # it, every rank gets the whole buffer) and load_state_dict() keeps this rank's rows.
+    collective_state_dict = True
+
+    def _indexed_params(self):
+        i = 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                yield i, p
+                i += 1
+
+    @torch.no_grad()
+    def state_dict(self):
+        sd = super().state_dict()
+        for i, p in self._indexed_params():
+            st = sd["state"].get(i)
+            if not st or "exp_avg" not in st:
+                continue
+            buf = st["exp_avg"]
+            lo, hi, shared = self._rows_of(p)
+            if shared:
+                buf = parallel.all_gather_rows(buf.contiguous())
+            sd["state"][i] = dict(st, exp_avg=buf.reshape(p.shape))
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for _, p in self._indexed_params():
+            st = self.state.get(p)
+            if not st:
+                continue
+            if "momentum_buffer" in st and "exp_avg" not in st:     # this package's key before round 3
+                st["exp_avg"] = st.pop("momentum_buffer")
+            if "exp_avg" not in st:
+                continue
+            R = p.shape[0]
+            C = p.numel() // R
+            lo, hi, _ = self._rows_of(p)
+            buf = st["exp_avg"]
+            if buf.numel() == p.numel():
+                st["exp_avg"] = buf.reshape(R, C)[lo:hi].to(torch.float32).contiguous().clone()
+            elif tuple(buf.shape) == (hi - lo, C):
+                st["exp_avg"] = buf.to(torch.float32).contiguous()
+            else:
+                raise ValueError(f"Muon: momentum state of shape {tuple(buf.shape)} fits neither the parameter "
+                                 f"{tuple(p.shape)} nor this rank's rows ({hi - lo}, {C}): a checkpoint written by one "
+                                 "rank of a row-sharded run before the state was gathered on save")
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None, "Closure is not supported."
@@ -117,9 +169,9 @@ class Muon(torch.optim.Optimizer):
                 g = g if g.is_contiguous() else g.contiguous()
                 lo, hi, shared = self._rows_of(p)
                 st = self.state[p]
-                if beta > 0 and "momentum_buffer" not in st:
-                    st["momentum_buffer"] = torch.zeros(hi - lo, C, dtype=torch.float32, device=p.device)
-                u, norm = ops.muon_momentum(g[lo:hi], st.get("momentum_buffer"), beta, group["nesterov"])
+                if beta > 0 and "exp_avg" not in st:                 # the reference's key, muon.py:154-157
+                    st["exp_avg"] = torch.zeros(hi - lo, C, dtype=torch.float32, device=p.device)
+                u, norm = ops.muon_momentum(g[lo:hi], st.get("exp_avg"), beta, group["nesterov"])
                 if shared:
                     parallel.all_reduce_(norm[:1], "sum")           # Frobenius norm over all rows
                     ops.muon_denominator_(norm)

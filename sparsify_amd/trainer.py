@@ -489,7 +489,8 @@ class Trainer:
             for i, scheduler in enumerate(self.lr_schedulers):
                 torch.save(scheduler.state_dict(), f"{path}/lr_scheduler_{i}.pt")
             for i, optimizer in enumerate(self.optimizers):
-                torch.save(optimizer.state_dict(), f"{path}/optimizer_{i}.pt")
+                state = getattr(self, "_opt_states", {}).get(i)
+                torch.save(state if state is not None else optimizer.state_dict(), f"{path}/optimizer_{i}.pt")
             torch.save({"global_step": self.global_step}, f"{path}/state.pt")
             self.cfg.save_json(f"{path}/config.json")
         for optimizer in self.optimizers:
@@ -499,9 +500,20 @@ class Trainer:
         torch.save({"num_tokens_since_fired": self.num_tokens_since_fired, "best_loss": self.best_loss},
                    f"{path}/rank_{rank}_state.pt")
 
+    def _collect_optimizer_states(self):
+        """Optimizers whose state is split over the ranks (row-sharded Muon) gather it in state_dict():
+        a collective, so every rank calls it, whoever writes the file (rank 0, trainer.py:663-668)."""
+        self._opt_states = {}
+        if self.cfg.save_dir and self.ddp:
+            parallel.wait_for_updates()
+            for i, optimizer in enumerate(self.optimizers):
+                if getattr(optimizer, "collective_state_dict", False):
+                    self._opt_states[i] = optimizer.state_dict()
+
     def save(self):
         path = f'{self.cfg.save_dir}/{self.cfg.run_name or "unnamed"}'
         rank_zero = not dist.is_initialized() or dist.get_rank() == 0
+        self._collect_optimizer_states()
         if self.cfg.save_dir and (rank_zero or self.cfg.distribute_modules or self.cfg.shard_latents):
             Path(path).mkdir(parents=True, exist_ok=True)
             self._checkpoint(self.saes, path, rank_zero)
@@ -519,11 +531,13 @@ class Trainer:
             for name in self.saes:
                 if avg_loss[name] < self.best_loss[name]:
                     self.best_loss[name] = avg_loss[name]
+                    self._collect_optimizer_states()          # (the averaged losses agree on all ranks)
                     if writer:
                         Path(f"{base_path}/{name}").mkdir(parents=True, exist_ok=True)
                         self._checkpoint({name: self.saes[name]}, f"{base_path}/{name}", rank_zero)
         elif avg_loss < self.best_loss:
             self.best_loss = avg_loss
+            self._collect_optimizer_states()
             if writer:
                 Path(base_path).mkdir(parents=True, exist_ok=True)
                 self._checkpoint(self.saes, base_path, rank_zero)

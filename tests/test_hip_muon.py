@@ -157,7 +157,7 @@ def _run_muon(ddp):
         p.grad, q.grad = gp.clone().cuda(), gq.clone().cuda()
         opt.step()
     torch.cuda.synchronize()
-    return p.detach().cpu(), q.detach().cpu(), tuple(opt.state[p]["momentum_buffer"].shape)
+    return p.detach().cpu(), q.detach().cpu(), tuple(opt.state[p]["exp_avg"].shape)
 
 
 def _muon_worker(rank, world, port, ret):
@@ -196,3 +196,82 @@ def test_row_sharded_muon_two_ranks(device):
     torch.testing.assert_close(ret[0][0], one[0], rtol=0, atol=3 * 2e-2 * step)
     assert float((ret[0][0] - one[0]).abs().mean()) < 3 * 5e-3 * step
     assert torch.equal(ret[0][1], one[1])                               # not sharded: the same kernels on the same data
+
+
+def _muon_resume_worker(rank, world, port, ret, save_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparsify_amd import SparseCoderConfig, TrainConfig
+        from sparsify_amd.trainer import SyntheticActivations, Trainer
+        D, M, k, N, steps, cut = 256, 4096, 16, 512, 5, 3
+
+        def make():
+            cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="muon", hookpoints=["h0"], lr_warmup_steps=2,
+                              save_dir=save_dir, run_name="run", save_every=10**9, wandb_log_frequency=1)
+            src = SyntheticActivations(["h0"], D, N, steps, device="cuda", rank=rank)
+            torch.manual_seed(0)
+            return Trainer(cfg, src, device="cuda"), src
+
+        tr, src = make()                                   # the uninterrupted run
+        for s in range(steps):
+            tr.train_micro_batch(src.batch(s))
+        torch.cuda.synchronize()
+        straight = {n: p.detach().cpu() for n, p in tr.saes["h0"].named_parameters()}
+
+        tr, src = make()                                   # the same run, saved after `cut` steps ...
+        for s in range(cut):
+            tr.train_micro_batch(src.batch(s))
+        muon = tr.optimizers[0]
+        w = tr.saes["h0"].encoder.weight
+        rows_before = muon.state[w]["exp_avg"].detach().cpu().clone()
+        tr.save()
+        tr2, src = make()                                  # ... and resumed by a fresh Trainer
+        tr2.load_state(f"{save_dir}/run")
+        assert tr2.global_step == cut
+        w2 = tr2.saes["h0"].encoder.weight
+        rows_after = tr2.optimizers[0].state[w2]["exp_avg"].detach().cpu().clone()
+        for s in range(cut, steps):
+            tr2.train_micro_batch(src.batch(s))
+        torch.cuda.synchronize()
+        resumed = {n: p.detach().cpu() for n, p in tr2.saes["h0"].named_parameters()}
+        ret[rank] = dict(straight=straight, resumed=resumed, rows_before=rows_before, rows_after=rows_after,
+                         range=muon._rows_of(w))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_muon_resume_two_ranks(device, tmp_path):
+    """The momentum of a row-sharded data-parallel Muon run survives a checkpoint: rank 0 writes
+    optimizer_0.pt in the reference's format (state key `exp_avg`, the whole parameter's shape:
+    muon.py:154-157, trainer.py:663-668) from the gathered row shards, every rank cuts its own rows back
+    out on load -- rank 1's are its own, not rank 0's -- and the resumed run ends on bit for bit the
+    parameters of the uninterrupted one."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_muon_resume_worker, args=(r, 2, port, ret, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank did not finish (collective mismatch?)")
+        assert p.exitcode == 0
+    sd = torch.load(tmp_path / "run" / "optimizer_0.pt", map_location="cpu", weights_only=True)
+    bufs = [st["exp_avg"] for st in sd["state"].values()]
+    assert sorted(tuple(b.shape) for b in bufs) == [(4096, 256), (4096, 256)]          # encoder.weight and W_dec, whole
+    assert all("momentum_buffer" not in st for st in sd["state"].values())
+    for r in (0, 1):
+        lo, hi, shared = ret[r]["range"]
+        assert shared and (lo, hi) == (2048 * r, 2048 * (r + 1))
+        assert torch.equal(ret[r]["rows_before"], ret[r]["rows_after"]), f"rank {r} resumed with other momentum rows"
+        assert any(torch.equal(b[lo:hi], ret[r]["rows_before"]) for b in bufs)
+        for name, want in ret[r]["straight"].items():
+            assert torch.equal(ret[r]["resumed"][name], want), f"rank {r}: {name} differs after the resume"
+    assert not torch.equal(ret[0]["rows_before"], ret[1]["rows_before"])
+    for name, a in ret[0]["resumed"].items():
+        assert torch.equal(a, ret[1]["resumed"][name])
