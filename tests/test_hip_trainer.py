@@ -446,3 +446,27 @@ def test_adam_step_vs_torch_adam(device, n):
         assert torch.equal(sh, p.bfloat16())
         with pytest.raises(Exception):
             ops.adam_step_(p, grads[0].cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0)
+
+
+def test_fused_encoder_update_refuses_a_second_backward(device):
+    """With `fuse_encoder_update` the SignSGD step of encoder.weight happens inside
+    FusedEncoder.backward. A second backward through the same (retained) graph would step twice on a
+    gradient taken at the old weights: autograd must refuse it (the update bumps the parameter's version,
+    which invalidates the tensors the graph saved), and the parameter must hold exactly one step."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N = 64, 512, 8, 256
+    x = make_batches(1, N, D)[0].cuda()
+    cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer="signsgd", lr=1e-3, save_dir="", save_every=10**9)
+    tr = Trainer(cfg, ListSource([x], D), device="cuda")
+    sae = tr.saes["h0"]
+    w0 = sae.encoder.weight.detach().clone()
+    out = sae(x=x, y=x)
+    out.fvu.backward(retain_graph=True)
+    assert sae.encoder.weight.grad is None, "the fused update was expected to run inside the backward"
+    w1 = sae.encoder.weight.detach().clone()
+    moved = (w1 - w0).abs()
+    assert float(moved.max()) == pytest.approx(1e-3, rel=1e-3) and bool(((moved == 0) | ((moved - 1e-3).abs() < 1e-6)).all())
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.fvu.backward()
+    assert torch.equal(sae.encoder.weight.detach(), w1), "a refused backward must not have touched the parameter"
