@@ -341,17 +341,50 @@ def shard_range(num_latents: int, r: int | None = None, w: int | None = None) ->
     return r * per, (r + 1) * per
 
 
+def pack_candidates(vals: Tensor, gidx: Tensor) -> Tensor:
+    """(value, global index) pairs as one int64 record each: the value's bits (bf16 or fp32) in the
+    upper half, the index (< 2^32) in the lower. 8 bytes per candidate on the wire, one message."""
+    if vals.dtype == torch.bfloat16:
+        bits = (vals.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 48
+    elif vals.dtype == torch.float32:
+        bits = (vals.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF) << 32
+    else:
+        raise TypeError(f"pack_candidates: bf16 or fp32 values, got {vals.dtype}")
+    return bits | gidx.to(torch.int64)
+
+
+def unpack_candidates(packed: Tensor, dtype: torch.dtype) -> tuple[Tensor, Tensor]:
+    """Inverse of pack_candidates: (values of `dtype`, int64 indices), both shaped like `packed`."""
+    if dtype == torch.bfloat16:
+        vals = (packed >> 48).to(torch.int16).view(torch.bfloat16)
+    else:
+        vals = (packed >> 32).to(torch.int32).view(torch.float32)
+    return vals, packed & 0xFFFFFFFF
+
+
+def candidate_indices(cand_i: Tensor, pos: Tensor) -> Tensor:
+    """Global indices of the merged selection: `pos` (N, k) are positions in a token's shard-major
+    candidate list of W*kk entries; `cand_i` is (N, W*kk), or the (N, W, kk) view of the gathered
+    rank-major records, which is indexed in place (no transposed copy of the indices)."""
+    if cand_i.ndim == 2:
+        return cand_i.gather(1, pos)
+    kk = cand_i.shape[2]
+    rows = torch.arange(cand_i.shape[0], device=cand_i.device)[:, None]
+    return cand_i[rows, pos // kk, pos % kk]
+
+
 def gather_topk_candidates(local_vals: Tensor, local_idx: Tensor, lo: int) -> tuple[Tensor, Tensor]:
-    """All-gather every shard's k local candidates as (value, global index) pairs:
-    (N, k) per rank -> (N, W*k). W*N*k*(2..4 + 8) bytes on the wire."""
+    """All-gather every shard's k local candidates as packed (value, global index) records:
+    (N, k) per rank -> values (N, W*k), shard-major per token, and indices as the (N, W, k) view of the
+    gathered records (see candidate_indices). One collective, W*N*k*8 bytes on the wire (SURVEY.md 8e:
+    6-8 bytes per candidate; it was two collectives and 10-12 bytes with int64 indices)."""
     gidx = local_idx + lo
     if world_size() == 1:
         return local_vals, gidx
     w = world_size()
     N, k = local_vals.shape
-    vals = local_vals.new_empty(w * N, k)
-    idxs = gidx.new_empty(w * N, k)
-    _all_gather_raw(vals, local_vals.contiguous())
-    _all_gather_raw(idxs, gidx.contiguous())
-    return (vals.view(w, N, k).permute(1, 0, 2).reshape(N, w * k),
-            idxs.view(w, N, k).permute(1, 0, 2).reshape(N, w * k))
+    mine = pack_candidates(local_vals, gidx)
+    got = mine.new_empty(w * N, k)
+    _all_gather_raw(got, mine)
+    vals, idxs = unpack_candidates(got.view(w, N, k), local_vals.dtype)
+    return vals.permute(1, 0, 2).reshape(N, w * k), idxs.permute(1, 0, 2)

@@ -47,7 +47,7 @@ def merge_candidates(cand_v: Tensor, cand_i: Tensor, k: int, lo: int, hi: int):
     row. The local view holds `index - lo` for the latents this rank owns and -1 (inactive slot,
     see sphip_gather_rows_weighted) elsewhere."""
     mv, mpos = ops.topk(cand_v.contiguous(), k)
-    gidx = cand_i.gather(1, mpos)
+    gidx = parallel.candidate_indices(cand_i, mpos)
     mine = (gidx >= lo) & (gidx < hi)
     local_idx = torch.where(mine, gidx - lo, torch.full_like(gidx, -1))
     return mv, gidx, local_idx

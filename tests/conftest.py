@@ -42,3 +42,31 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+TOY_WORDS = ("the of and to in is that it was for on are as with his they at be this from have or by one had not but what "
+             "all were when we there can an your which their said if do will each about how up out them then she many some "
+             "so these would other into has more her two like him see time could no make than first been its who now "
+             "people my made over did down only way find use may water long little very after words called just where").split()
+
+
+def toy_tokenizer(model_max_length: int = 64):
+    """A word-level fast tokenizer over a fixed vocabulary (no download, no training): what
+    tools/make_golden.py fed the reference's chunk_and_tokenize and what the test feeds ours."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<|endoftext|>": 0, "<unk>": 1, **{w: i + 2 for i, w in enumerate(TOY_WORDS)}}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    return PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|endoftext|>", unk_token="<unk>",
+                                   model_max_length=model_max_length)
+
+
+def toy_documents(n: int = 300, seed: int = 0) -> list[str]:
+    import random
+    rng = random.Random(seed)
+    docs = []
+    for _ in range(n):
+        words = [rng.choice(TOY_WORDS) if rng.random() > 0.03 else "zyx" for _ in range(rng.choice([1, 3, 7, 20, 45, 120]))]
+        docs.append(" ".join(words))
+    return docs

@@ -294,3 +294,39 @@ def test_memmap_dataset(tmp_path):
     assert [len(p) for p in parts] == [4, 3, 3] and torch.equal(parts[1][0]["input_ids"], ds[4]["input_ids"])
     batch = next(iter(DataLoader(ds, batch_size=4)))
     assert batch["input_ids"].shape == (4, 16)
+
+
+@pytest.mark.parametrize("name,kw,model_max", [("rows16", dict(max_seq_len=16), 64),
+                                               ("rows16_tail", dict(max_seq_len=16, return_final_batch=True), 64),
+                                               ("model_max_24", dict(max_seq_len=2048), 24)])
+def test_chunk_and_tokenize_vs_reference(name, kw, model_max):
+    """sparsify_amd.data.chunk_and_tokenize against the rows the reference's own function produced
+    (sparsify/data.py:14-101 through tools/make_golden.py -> tests/golden/tokenize.json) on the same
+    word-level tokenizer and documents: same rows, same order, `input_ids` the only column."""
+    import json
+    from datasets import Dataset
+    from conftest import GOLDEN, toy_documents, toy_tokenizer
+    from sparsify_amd.data import chunk_and_tokenize
+    want = json.loads((GOLDEN / "tokenize.json").read_text())[name]
+    docs = toy_documents()
+    ds = chunk_and_tokenize(Dataset.from_dict({"text": docs, "other": list(range(len(docs)))}), toy_tokenizer(model_max),
+                            num_proc=1, load_from_cache_file=False, **kw)
+    assert ds.column_names == ["input_ids"]
+    got = [row["input_ids"] for row in ds]
+    assert all(isinstance(r, torch.Tensor) and r.dtype == torch.int64 for r in got)
+    assert [r.tolist() for r in got] == want
+    row_len = min(model_max, kw["max_seq_len"])
+    assert all(len(r) == row_len for r in want[:-1]) and want[0][0] == 0          # starts with the end-of-text token
+    assert (len(want[-1]) < row_len) == bool(kw.get("return_final_batch")) or len(want[-1]) == row_len
+
+
+def test_chunk_and_tokenize_too_little_data():
+    from datasets import Dataset
+    from conftest import toy_tokenizer
+    from sparsify_amd.data import chunk_and_tokenize
+    with pytest.raises(ValueError, match="Not enough data"):
+        chunk_and_tokenize(Dataset.from_dict({"text": ["the of and"]}), toy_tokenizer(), num_proc=1, max_seq_len=16,
+                           load_from_cache_file=False)
+    ds = chunk_and_tokenize(Dataset.from_dict({"text": ["the of and"]}), toy_tokenizer(), num_proc=1, max_seq_len=16,
+                            return_final_batch=True, load_from_cache_file=False)
+    assert [r["input_ids"].tolist() for r in ds] == [[0, 2, 3, 4]]

@@ -141,7 +141,8 @@ def _sharded_topk(rank, world):
     vals, gidx = P.gather_topk_candidates(lv, li, lo)
     assert vals.shape == (N, world * k)
     mv, mpos = vals.topk(k, dim=-1)                # merge (ops.topk on the GPU path)
-    midx = gidx.gather(1, mpos)
+    assert gidx.shape == (N, world, k)             # the (token, shard, slot) view of the gathered 8-byte records
+    midx = P.candidate_indices(gidx, mpos)
     ref = pre.topk(k, dim=-1)
     return torch.equal(mv, ref.values) and torch.equal(midx.sort(-1).values, ref.indices.sort(-1).values)
 
@@ -194,3 +195,26 @@ def test_sign_exchange_equals_step_on_mean_gradient():
     for ok_plain, frac_bad, block_ok in launch(_sign_exchange):
         assert ok_plain and block_ok
         assert frac_bad < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_candidate_records_round_trip(dtype):
+    """The latent-shard exchange ships one 8-byte record per candidate (value bits | global index):
+    packing and unpacking is exact for every value (negative, -inf for masked-out latents, zeros) and for
+    indices up to the widest dictionary."""
+    from sparsify_amd import parallel as P
+    g = torch.Generator().manual_seed(0)
+    vals = torch.randn(37, 11, generator=g).to(dtype)
+    vals[0, :3] = torch.tensor([float("-inf"), 0.0, -0.0]).to(dtype)
+    idx = torch.randint(0, 2**31 - 1, (37, 11), generator=g)
+    idx[1, :2] = torch.tensor([0, 2**32 - 1])
+    rec = P.pack_candidates(vals, idx)
+    assert rec.dtype == torch.int64 and rec.element_size() == 8 and rec.shape == vals.shape
+    v2, i2 = P.unpack_candidates(rec, dtype)
+    assert v2.dtype == dtype and torch.equal(v2.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                                             vals.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+    assert torch.equal(i2, idx)
+    pos = torch.randint(0, 2 * 11, (37, 5), generator=g)
+    flat = torch.cat([idx, idx + 1], 1)                                   # two "shards", shard-major per token
+    view = torch.stack([idx, idx + 1], 0).permute(1, 0, 2)                # the gathered (W, N, k) records seen as (N, W, k)
+    assert not view.is_contiguous() and torch.equal(P.candidate_indices(view, pos), flat.gather(1, pos))

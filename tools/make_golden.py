@@ -373,10 +373,32 @@ def gen_checkpoint():
         print(f"  reverse interop ({tag}): build-written checkpoint loads in the reference, equal")
 
 
+def gen_tokenize():
+    """sparsify/data.py:14-101 on the toy tokenizer and documents of tests/conftest.py: the rows the
+    reference's chunk_and_tokenize produces, for three settings."""
+    import json
+
+    from datasets import Dataset
+    from sparsify.data import chunk_and_tokenize
+    sys.path.insert(0, str(OUT.parent))
+    from conftest import toy_documents, toy_tokenizer
+    docs = toy_documents()
+    out = {}
+    for name, kw, max_len in (("rows16", dict(max_seq_len=16), 64), ("rows16_tail", dict(max_seq_len=16, return_final_batch=True), 64),
+                              ("model_max_24", dict(max_seq_len=2048), 24)):
+        ds = chunk_and_tokenize(Dataset.from_dict({"text": docs, "other": list(range(len(docs)))}), toy_tokenizer(max_len),
+                                num_proc=1, load_from_cache_file=False, **kw)
+        # (a fast tokenizer's `overflow_to_sample_mapping` stays as a hidden column: the format shows input_ids only)
+        assert all(list(row) == ["input_ids"] for row in ds), ds.column_names
+        out[name] = [[int(t) for t in row["input_ids"]] for row in ds]
+        print(f"  tokenize/{name}: {len(out[name])} rows, last of {len(out[name][-1])}")
+    (OUT / "tokenize.json").write_text(json.dumps(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encoder", "decode", "coder", "dense", "muon", "trajectory", "checkpoint"]
+    which = sys.argv[1:] or ["encoder", "decode", "coder", "dense", "muon", "trajectory", "checkpoint", "tokenize"]
     table = dict(encoder=gen_encoder, decode=gen_decode, coder=gen_sparse_coder, dense=gen_dense,
-                 muon=gen_muon, trajectory=gen_trajectory, checkpoint=gen_checkpoint)
+                 muon=gen_muon, trajectory=gen_trajectory, checkpoint=gen_checkpoint, tokenize=gen_tokenize)
     for w in which:
         print(f"[{w}]")
         table[w]()
