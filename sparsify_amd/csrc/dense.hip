@@ -736,7 +736,7 @@ namespace sphip {
 // v.mul_(b2).addcmul_(g, g, 1 - b2); denom = sqrt(v) / sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr / bc1).
 __device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v, float w1, float b2, float w2,
                                            float step_size, float bc2_sqrt, float eps) {
-    m = __fmaf_rn(w1, g - m, m);                           // lerp, weight < 0.5: start + weight * (end - start)
+    m = lerpf(m, g, w1);                                   // torch.lerp's two branches (common.hpp): beta1 <= 0.5 takes the other
     v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(w2, g), g));
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
     p = __fadd_rn(p, __fmul_rn(-step_size, __fdiv_rn(m, denom)));

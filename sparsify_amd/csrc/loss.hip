@@ -298,6 +298,16 @@ extern "C" int sphip_total_variance_static(const void* y, int y_dtype, int64_t N
     int dev = -1;
     SPHIP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEV, SPHIP_ELAUNCH,
                   "total_variance_static: no current device");
+    // the scratch used is the CURRENT device's copy: the data and the stream must live there too (another
+    // GPU's kernels would be handed this one's array: peer access at best, a fault otherwise)
+    hipPointerAttribute_t attr;
+    SPHIP_REQUIRE(y != nullptr && hipPointerGetAttributes(&attr, y) == hipSuccess && attr.device == dev, SPHIP_EINVAL,
+                  "total_variance_static: y is not memory of the current device %d (hipSetDevice to the data's GPU first)", dev);
+    if (stream != nullptr) {
+        hipDevice_t sdev = -1;
+        SPHIP_REQUIRE(hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && (int)sdev == dev, SPHIP_EINVAL,
+                      "total_variance_static: the stream belongs to device %d, the current device is %d", (int)sdev, dev);
+    }
     void* ptr;
     {
         std::lock_guard<std::mutex> lock(mu);

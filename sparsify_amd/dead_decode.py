@@ -42,9 +42,28 @@ def eligible(pre_acts: Tensor, k_aux: int, W_dec: Tensor, num_dead: int) -> bool
 # addition by the autograd engine at the headline shape, 1.6 ms -- it parks its (n_dead, D) rows
 # here, keyed by the parameter's storage address (validated through a weak reference), and
 # utils.SparseDecode.backward adds them into the dense gradient it returns (claim_pending_rows).
-# A callback queued on the autograd engine settles whatever is
-# still parked when the backward pass ends (no main decode in the graph): it then goes into
-# W_dec.grad directly.
+# Rows are parked only when that backward is certain to come: the forward notes the main decode's
+# autograd node (note_decode), and DeadLatentDecode.backward asks the engine whether it will execute
+# that node in this very pass. Otherwise (auxk_loss back-propagated on its own, torch.autograd.grad
+# over a sub-graph) it returns the dense zero-filled gradient like any other op, so W_dec.grad is only
+# ever written by the engine's own accumulation, with every hook that hangs on it (gradient reducers,
+# the sign exchange's early start). The callback below is a safety net for a pass that died half-way.
+_decode_nodes: dict[int, tuple] = {}
+
+
+def note_decode(weight: Tensor, node) -> None:
+    """The autograd node of the latest row-gather decode over `weight` (SparseCoder.decode)."""
+    if node is not None:
+        _decode_nodes[weight.data_ptr()] = (weakref.ref(weight), weakref.ref(node))
+
+
+def _latest_decode_node(weight: Tensor):
+    hit = _decode_nodes.get(weight.data_ptr())
+    if hit is None or hit[0]() is not weight:
+        return None
+    return hit[1]()
+
+
 _pending_rows: dict[int, list] = {}
 
 
@@ -92,6 +111,7 @@ class DeadLatentDecode(torch.autograd.Function):
             ops.gemm_bf16_f32acc(A, w_parts[p], out, accumulate=True)
         ctx.save_for_backward(At, dead_list)
         ctx.weight_ref = weakref.ref(W_dec) if isinstance(W_dec, torch.nn.Parameter) else None
+        ctx.main_node = _latest_decode_node(W_dec)      # (both nodes belong to the same forward's graph)
         ctx.dims = (N, M, D, num_dead)
         ctx.set_materialize_grads(False)
         return out
@@ -110,7 +130,9 @@ class DeadLatentDecode(torch.autograd.Function):
             for p in range(3):
                 ops.gemm_bf16_f32acc(At, g_parts[p], G, accumulate=p > 0)
             w = ctx.weight_ref() if ctx.weight_ref is not None else None
-            if w is not None and w.is_leaf:
+            claimed = (w is not None and w.is_leaf and ctx.main_node is not None
+                       and torch._C._will_engine_execute_node(ctx.main_node))
+            if claimed:
                 _pending_rows.setdefault(w.data_ptr(), []).append((ctx.weight_ref, G, dead_list, num_dead))
                 torch.autograd.Variable._execution_engine.queue_callback(_settle_pending_rows)
             else:

@@ -218,6 +218,9 @@ def lazy_eligible(N: int, D: int, M: int, k: int) -> bool:
             and encoder_preacts_uses_tile256(N, D, Ma))
 
 
+LAZY_REDO_ROWS = 2048          # tokens per launch of the predicated fallback of encode_topk_lazy
+
+
 def encode_topk_lazy(x: Tensor, W: Tensor, bias: Tensor | None, k: int, fallback: bool = True):
     """top-k of relu(x @ W.T + bias) without storing the (N, M) matrix (include/sparsify_hip.h,
     "top-k without the (N, M) matrix"; fused_encoder.py:29-33 when pre_acts is not read).
@@ -260,14 +263,20 @@ def encode_topk_lazy(x: Tensor, W: Tensor, bias: Tensor | None, k: int, fallback
     timer.stop(_ev, x)
     flag = ws[:4].view(torch.int32)
     if fallback:
-        # 5. predicated: both launches return at once unless the flag is up
-        full = _workspace(x.device, N * M * 2, "lazy_full").view(torch.bfloat16)[:N * M].view(N, M)
+        # 5. predicated: the launches return at once unless the flag is up. The redo runs LAZY_REDO_ROWS
+        # tokens at a time through one small workspace (512 MiB at M = 131072): reserving the whole
+        # (N, M) matrix for a path that almost never runs would hold more memory than the ordinary
+        # forward, whose pre-activations go back to the allocator after every step
+        R = min(N, LAZY_REDO_ROWS)
+        full = _workspace(x.device, R * M * 2, "lazy_full").view(torch.bfloat16)
         T = -(-M // TOPK_TILE)
-        tm = _workspace(x.device, -(-N // 64) * T * 64 * 2, "lazy_full_tmax")
-        check(lib.sphip_encoder_preacts_if(flag.data_ptr(), x.data_ptr(), W.data_ptr(), _ptr(bias), full.data_ptr(),
-                                           tm.data_ptr(), N, D, M, 1, st), "sphip_encoder_preacts_if")
-        check(lib.sphip_topk_if(flag.data_ptr(), full.data_ptr(), BF16, None, tm.data_ptr(), N, M, k, vals.data_ptr(),
-                                idx.data_ptr(), st), "sphip_topk_if")
+        tm = _workspace(x.device, -(-R // 64) * T * 64 * 2, "lazy_full_tmax")
+        for r0 in range(0, N, R):
+            n = min(R, N - r0)
+            check(lib.sphip_encoder_preacts_if(flag.data_ptr(), x[r0:r0 + n].data_ptr(), W.data_ptr(), _ptr(bias),
+                                               full.data_ptr(), tm.data_ptr(), n, D, M, 1, st), "sphip_encoder_preacts_if")
+            check(lib.sphip_topk_if(flag.data_ptr(), full.data_ptr(), BF16, None, tm.data_ptr(), n, M, k,
+                                    vals[r0:r0 + n].data_ptr(), idx[r0:r0 + n].data_ptr(), st), "sphip_topk_if")
     return vals, idx, flag
 
 

@@ -249,6 +249,7 @@ class SparseCoder(nn.Module):
         keep_bf16 = top_acts.dtype == torch.bfloat16 and self.W_dec.dtype == torch.float32
         acts = (top_acts if keep_bf16 else top_acts.to(self.dtype)).reshape(-1, top_acts.shape[-1])
         y = SparseDecode.apply(idx, self.W_dec, acts, self.b_dec)
+        dead_decode.note_decode(self.W_dec, y.grad_fn)      # whose backward takes the AuxK rows along (dead_decode.py)
         return y.reshape(*top_indices.shape[:-1], self.d_in)
 
     # Same autocast wrapper as the reference (sparse_coder.py:204-209): the encoder linear

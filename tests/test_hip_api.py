@@ -194,6 +194,33 @@ def test_auxk_dense_gradient_rows_without_a_main_decode_backward(device, monkeyp
     assert gW[~g["dead_mask"]].abs().max() == 0 and gW[g["dead_mask"]].abs().max() > 0
 
 
+def test_auxk_dense_gradient_reaches_hooks_on_w_dec(device, monkeypatch):
+    """W_dec.grad is only ever written by the autograd engine's own accumulation, so hooks that hang
+    on it (parallel.GradReducer's post-accumulate hook, which starts an all-reduce of the gradient it is
+    handed; the sign exchange's early start) see the complete gradient exactly once -- with the AuxK
+    decode next to the main decode (rows ride in the main decode's gradient), with auxk_loss
+    back-propagated on its own (dense zero-filled gradient, nothing parked), and under
+    torch.autograd.grad, which must leave .grad alone."""
+    from sparsify_amd import dead_decode
+    monkeypatch.setenv("SPHIP_AUXK", "dense")
+    name = [n for n in golden_names("coder_") if "_bf16_" in n and "fewdead" in n][0]
+    g = load_golden(name)
+    for alone in (False, True):
+        sae, mode = build_sae(g, name)
+        seen = []
+        sae.W_dec.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone()))
+        out = run_coder(sae, mode, g["x"].cuda(), g["y"].cuda() if "y" in g else None, g["dead_mask"].cuda())
+        (out.auxk_loss if alone else out.fvu + g["alpha"] * out.auxk_loss).backward()
+        assert len(seen) == 1 and torch.equal(seen[0], sae.W_dec.grad), "a hook saw an incomplete W_dec gradient"
+        assert not dead_decode._pending_rows
+        assert sae.W_dec.grad[g["dead_mask"].cuda()].abs().max() > 0
+    sae, mode = build_sae(g, name)
+    out = run_coder(sae, mode, g["x"].cuda(), g["y"].cuda() if "y" in g else None, g["dead_mask"].cuda())
+    (gW,) = torch.autograd.grad(out.auxk_loss, [sae.W_dec])
+    assert sae.W_dec.grad is None and not dead_decode._pending_rows
+    assert gW[~g["dead_mask"].cuda()].abs().max() == 0 and gW[g["dead_mask"].cuda()].abs().max() > 0
+
+
 def check_bf16_golden(name):
     """bf16 autocast. (a) the chosen top-k sets equal the reference's except at near ties of
     the k-th boundary (north_star rule); (b) on rows with identical sets, values and

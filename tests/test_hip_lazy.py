@@ -79,11 +79,14 @@ def test_lazy_topk_with_rows_full_of_ties():
         _same_selection((vals2, idx2), want)
 
 
-def test_lazy_topk_overflow_takes_the_predicated_fallback():
+@pytest.mark.parametrize("redo_rows", [2048, 96])
+def test_lazy_topk_overflow_takes_the_predicated_fallback(monkeypatch, redo_rows):
     """The first M/4 latents are all inactive (threshold 0), every other chunk holds a positive
     value: 6144 chunks per token against a capacity of 4096. The flag goes up and the
-    predicated launches behind it produce the ordinary path's result."""
+    predicated launches behind it produce the ordinary path's result -- in one piece, or 96 tokens
+    at a time through the fixed-size workspace (ops.LAZY_REDO_ROWS; 256 tokens = 2 pieces + a tail)."""
     from sparsify_amd import ops
+    monkeypatch.setattr(ops, "LAZY_REDO_ROWS", redo_rows)
 
     N, D, M, k = 256, 64, 65536, 32
     x, W, b = _operands(N, D, M, seed=9)

@@ -397,8 +397,9 @@ def test_schedulefree_kernels_vs_independent_oracle(device, D):
     torch.testing.assert_close(x.cpu().double(), ora_e.eval_weights(), rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("betas", [(0.9, 0.999), (0.3, 0.95)])       # beta1 <= 0.5: torch.lerp's other branch
 @pytest.mark.parametrize("n", [1, 7, 4096 + 3, 300_001])
-def test_adam_step_vs_torch_adam(device, n):
+def test_adam_step_vs_torch_adam(device, n, betas):
     """sparsify_amd.adam.Adam (sphip_adam_step) against torch.optim.Adam (single-tensor, fp32, on the
     CPU and on the GPU) over ten steps with a changing learning rate; the state dictionaries are
     interchangeable, and the bf16 shadow is the rounded parameter, bit for bit. Tolerance: a few
@@ -411,8 +412,8 @@ def test_adam_step_vs_torch_adam(device, n):
     grads = [torch.randn(n, generator=gen) * (10.0 ** (i % 3 - 1)) for i in range(10)]
     ours = torch.nn.Parameter(p0.clone().cuda())
     refs = [torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone().cuda())]
-    opt = Adam([ours], lr=1e-3)
-    ropts = [torch.optim.Adam([r], lr=1e-3, foreach=False, fused=False) for r in refs]
+    opt = Adam([ours], lr=1e-3, betas=betas)
+    ropts = [torch.optim.Adam([r], lr=1e-3, betas=betas, foreach=False, fused=False) for r in refs]
     for i, g in enumerate(grads):
         for o in [opt] + ropts:
             o.param_groups[0]["lr"] = 1e-3 * (i + 1) / 10
@@ -428,9 +429,9 @@ def test_adam_step_vs_torch_adam(device, n):
     torch.testing.assert_close(st["exp_avg_sq"].cpu(), rst["exp_avg_sq"], rtol=2e-6, atol=1e-12)
     # torch's optimizer continues from our state dictionary, and ours from torch's
     cont = torch.nn.Parameter(ours.detach().clone())
-    copt = torch.optim.Adam([cont], lr=1e-3, foreach=False, fused=False)
+    copt = torch.optim.Adam([cont], lr=1e-3, betas=betas, foreach=False, fused=False)
     copt.load_state_dict(copy.deepcopy(opt.state_dict()))      # (load_state_dict aliases tensors already in place)
-    back = Adam([torch.nn.Parameter(ours.detach().clone())], lr=1e-3)
+    back = Adam([torch.nn.Parameter(ours.detach().clone())], lr=1e-3, betas=betas)
     back.load_state_dict(copy.deepcopy(copt.state_dict()))
     g = torch.randn(n, generator=gen).cuda()
     ours.grad, cont.grad = g, g.clone()
