@@ -269,3 +269,74 @@ def test_latent_sharded_trainer_matches_unsharded(device, tmp_path, variants):
     assert back.num_latents == 2048 and back.d_in == 128
     assert torch.equal(back.W_dec.detach(), torch.cat([r0["W_dec"], r1["W_dec"]]))
     assert torch.equal(back.encoder.weight.detach(), torch.cat([r0["W_enc"], r1["W_enc"]]))
+
+
+def _sign_exchange_worker(rank, world, port, backend, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparsify_amd import SignSGD, parallel
+        parallel.SignExchange.FORCE = True
+        ret[(backend, rank)] = _sign_exchange_steps(SignSGD, parallel, exchange=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def _sign_exchange_steps(SignSGD, parallel, exchange):
+    """Two optimizer steps on an encoder-like and a decoder-like matrix with the same gradients on
+    every rank. The gradients are bf16-representable, so the sum of eight equal copies and its
+    division by eight are exact: the rank-averaged gradient is the gradient itself, whatever the
+    order a backend adds in."""
+    M, D, lr = 16384, 256, 3e-3
+    gen = torch.Generator().manual_seed(5)
+    W_enc = torch.nn.Parameter(torch.randn(M, D, generator=gen).cuda())
+    W_dec = torch.randn(M, D, generator=gen)
+    W_dec = torch.nn.Parameter((W_dec / W_dec.norm(dim=1, keepdim=True)).cuda())
+    opt = SignSGD([dict(params=[W_dec], project_rows=True, renorm_rows=True), dict(params=[W_enc])], lr=lr,
+                  exchange_signs=exchange, overlap=exchange)
+    blocks = []
+    for _ in range(2):
+        W_enc.grad = torch.randn(M, D, generator=gen).bfloat16().float().cuda()
+        W_dec.grad = torch.randn(M, D, generator=gen).bfloat16().float().cuda()
+        opt.step()
+        blocks.append(len(parallel.pending_blocks(W_enc) or []))
+        parallel.wait_for_updates()
+        torch.cuda.synchronize()
+    return {"W_enc": W_enc.detach().cpu(), "W_dec": W_dec.detach().cpu(), "blocks": blocks,
+            "reduces": bool(opt.reduces(W_enc)) and bool(opt.reduces(W_dec))}
+
+
+def test_sign_exchange_rccl_one_rank_equals_eight_gloo_ranks(device):
+    """parallel.SignExchange on the same tensors over a real RCCL group of one rank (the overlapped
+    form: exchange stream, eight row blocks for the encoder matrix) and over eight gloo ranks (the
+    shard arithmetic of a full node: every rank reduces 1/8 of every row block, takes its signs, all
+    ranks apply all signs): bit-equal parameters on every rank, equal to the plain one-GPU SignSGD step
+    (projected gradient, sign step, re-normalisation for the decoder matrix)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    for backend, world in (("nccl", 1), ("gloo", 8)):
+        port = _free_port()
+        procs = [ctx.Process(target=_sign_exchange_worker, args=(r, world, port, backend, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=200)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                pytest.fail(f"a {backend} rank did not finish")
+            assert p.exitcode == 0
+    from sparsify_amd import SignSGD, parallel
+    plain = _sign_exchange_steps(SignSGD, parallel, exchange=False)
+    one = ret[("nccl", 0)]
+    assert one["reduces"] and one["blocks"] == [8, 8] and not plain["reduces"]
+    for name in ("W_enc", "W_dec"):
+        assert torch.equal(one[name], plain[name]), f"{name}: one-rank RCCL exchange != plain step"
+        for r in range(8):
+            got = ret[("gloo", r)]
+            assert got["reduces"] and torch.equal(got[name], one[name]), f"{name}: gloo rank {r} != RCCL one-rank"
+    assert ret[("gloo", 0)]["blocks"] == [8, 8]
