@@ -9,6 +9,8 @@ one needs to replay it: `python benchmarks/<name>_fuzz.py` walks the same sequen
   fused    fused encoder-gradient steps (SignSGD / schedule-free): bit for bit the separate path
   decoder  fused decoder steps: bit for bit the separate passes
   auxk     dense AuxK path against the row-gather decode: 2e-5
+  long     training-size shapes with power-law usage through the weight gradients (the chunked long-segment
+           path): 2e-5 of float64, fused steps bit for bit gradient + separate step, identical bits twice
 """
 import importlib.util
 from pathlib import Path
@@ -18,7 +20,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BENCH = Path(__file__).resolve().parent.parent / "benchmarks"
-CASES = {"topk": 200, "gemm": 150, "sparse": 80, "fused": 150, "decoder": 200, "auxk": 200}
+CASES = {"topk": 200, "gemm": 150, "sparse": 80, "fused": 150, "decoder": 200, "auxk": 200, "long": 24}
 ENV = ("SPHIP_GEMM", "SPHIP_GATHER", "SPHIP_WGRAD", "SPHIP_AUXK")
 
 
