@@ -192,11 +192,16 @@ int sphip_build_latent_segments(const int64_t* idx, int64_t N, int64_t k, int64_
  *   for gW only (the encoder input x - b_dec, sparse_coder.py:192, without materialising
  *   it: gW[j,:] = sum c*rows - (sum c)*row_shift).
  * coeff (N,k) of coeff_dtype, rows (N,D) of rows_dtype, W (M,D) fp32, outputs fp32.
- * Sums run in segment order, so results are bitwise reproducible.
+ * Sums run in a fixed order, so results are bitwise reproducible: a segment of up to 128 entries is
+ *   one chain in segment order; at training sizes (rows of 8 MiB and more) a longer one is cut into
+ *   128-entry chunks, each a chain, whose partial rows are added in chunk order (the reference's
+ *   atomics leave the order to arrival). gbias is the same sum from every entry point of this
+ *   family (sphip_segment_coeff_sums' order).
  * workspace (sphip_weight_grad_workspace_bytes): the segment-ordered (entry, coeff) list plus
  *   either a slice-major copy of rows (no dcoeff) or the per-column-slice partial dots of
- *   dcoeff (D/256 floats per entry), whichever is larger, plus the list of latents with very
- *   long segments (dense latents), which a second kernel takes over from the L2-sliced one. */
+ *   dcoeff (D/32 floats per entry), whichever is larger, plus the long-segment tables (list of
+ *   latents above 128 entries, chunk table, one partial row of D floats per chunk: at most
+ *   2*N*k/128 + 2 chunks). Take the size from the call. */
 size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D);
 int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                 int coeff_dtype, const void* rows, int rows_dtype, const float* W,
