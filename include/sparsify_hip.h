@@ -95,6 +95,16 @@ int sphip_encoder_preacts_block(const void* x, const void* W, const void* bias, 
 int sphip_topk(const void* pre, int dtype, const uint8_t* keep_mask, const void* tile_max,
                int64_t N, int64_t M, int64_t k, void* vals, int64_t* idx, void* stream);
 
+/* sparse_coder.py:256-262 (multi-top-k): `pre_acts.topk(4k)` holds the row's top-k set, whose rows
+ * the main decode (:201) has summed already. idx_out (N,kw) = idx_wide with every member of the
+ * narrower selection (vals_sel, idx_sel: N x k of the same row, by sphip_topk's set rule: all values
+ * above its smallest plus the lowest-index ties) replaced by -1, the inactive-slot mark of the decode
+ * and gradient entry points: decode(vals_wide, idx_out) + the main decode's output is the 4k
+ * reconstruction with 3k instead of 4k rows gathered per token. Order inside the rows is free. */
+int sphip_exclude_selected(const void* vals_wide, const int64_t* idx_wide, int64_t kw,
+                           const void* vals_sel, const int64_t* idx_sel, int64_t k, int dtype,
+                           int64_t N, int64_t* idx_out, void* stream);
+
 /* ---- top-k without the (N, M) matrix (fused_encoder.py:29-33 when nobody reads pre_acts;
  * the reference always materialises it, fused_encoder.py:50, and only AuxK / multi-top-k read it,
  * sparse_coder.py:230-262). bf16, relu, k <= 256, D % 64 == 0. Sequence for one batch, all on

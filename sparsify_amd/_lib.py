@@ -34,6 +34,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_encoder_preacts_block": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _P]),
     "sphip_topk": (_I, [_P, _I, _P, _P, _L, _L, _L, _P, _P, _P]),
     "sphip_groupmax": (_I, [_P, _I, _L, _L, _L, _P, _P, _P]),
+    "sphip_exclude_selected": (_I, [_P, _P, _L, _P, _P, _L, _I, _L, _P, _P]),
     "sphip_lazy_workspace_bytes": (_Z, [_L, _L]),
     "sphip_row_min": (_I, [_P, _L, _L, _P, _P]),
     "sphip_encoder_preacts_emit": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _L, _I, _P, _L, _P]),

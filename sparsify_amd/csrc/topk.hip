@@ -512,6 +512,38 @@ __global__ __launch_bounds__(256) void groupmax_kernel(const T* __restrict__ pre
     }
 }
 
+// Multi-top-k (sparse_coder.py:256-262): the wider selection contains the narrower one of the same
+// row, whose rows the main decode has already summed. A wave per token: the narrower selection's
+// last member in the order both selections are cut from (value descending, lowest index first) is
+// the minimum of (key << 32 | ~index) over its k entries; a wider entry at or above it is a member.
+template <typename T>
+__global__ __launch_bounds__(256) void exclude_selected_kernel(const T* __restrict__ vals_wide,
+                                                               const int64_t* __restrict__ idx_wide, int kw,
+                                                               const T* __restrict__ vals_sel,
+                                                               const int64_t* __restrict__ idx_sel, int k, int64_t N,
+                                                               int64_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    unsigned long long last = ~0ull;
+    for (int s = lane; s < k; s += 64) {
+        const int64_t i = idx_sel[n * k + s];
+        if (i < 0) continue;                       // an inactive slot selects nothing
+        const unsigned long long r = ((unsigned long long)to_key(vals_sel[n * k + s]) << 32) | (unsigned)(~(unsigned)i);
+        last = r < last ? r : last;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(last, o, 64);
+        last = other < last ? other : last;
+    }
+    for (int s = lane; s < kw; s += 64) {
+        const int64_t i = idx_wide[n * kw + s];
+        const unsigned long long r = ((unsigned long long)to_key(vals_wide[n * kw + s]) << 32) | (unsigned)(~(unsigned)i);
+        idx_out[n * kw + s] = (i >= 0 && r >= last) ? -1 : i;
+    }
+}
+
 }  // namespace sphip
 
 namespace sphip {
@@ -599,5 +631,26 @@ extern "C" int sphip_groupmax(const void* pre, int dtype, int64_t N, int64_t M, 
     else
         hipLaunchKernelGGL((groupmax_kernel<float>), grid, block, 0, s, (const float*)pre, (int)M, (int)k, (int)(M / k), total, (float*)vals, idx);
     SPHIP_CHECK_LAUNCH("groupmax");
+    return SPHIP_OK;
+}
+
+extern "C" int sphip_exclude_selected(const void* vals_wide, const int64_t* idx_wide, int64_t kw, const void* vals_sel,
+                                      const int64_t* idx_sel, int64_t k, int dtype, int64_t N, int64_t* idx_out,
+                                      void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(valid_dtype(dtype), SPHIP_EINVAL, "exclude_selected: bad dtype %d", dtype);
+    SPHIP_REQUIRE(vals_wide && idx_wide && vals_sel && idx_sel && idx_out, SPHIP_EINVAL, "exclude_selected: null pointer");
+    SPHIP_REQUIRE(N > 0 && k > 0 && kw >= k && kw < (1ll << 31), SPHIP_EINVAL, "exclude_selected: bad shape N=%lld k=%lld kw=%lld",
+                  (long long)N, (long long)k, (long long)kw);
+    SPHIP_REQUIRE(cdiv(N, 4) < (1ll << 31), SPHIP_EUNSUPPORTED, "exclude_selected: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(N, 4)), block(256);
+    if (dtype == SPHIP_BF16)
+        hipLaunchKernelGGL((exclude_selected_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)vals_wide, idx_wide, (int)kw,
+                           (const bf16_t*)vals_sel, idx_sel, (int)k, N, idx_out);
+    else
+        hipLaunchKernelGGL((exclude_selected_kernel<float>), grid, block, 0, s, (const float*)vals_wide, idx_wide, (int)kw,
+                           (const float*)vals_sel, idx_sel, (int)k, N, idx_out);
+    SPHIP_CHECK_LAUNCH("exclude_selected");
     return SPHIP_OK;
 }

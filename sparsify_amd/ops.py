@@ -200,6 +200,28 @@ def topk(pre: Tensor, k: int, keep_mask: Tensor | None = None, tile_max: Tensor 
     return vals, idx
 
 
+def exclude_selected(vals_wide: Tensor, idx_wide: Tensor, vals_sel: Tensor, idx_sel: Tensor) -> Tensor:
+    """idx_wide (N, kw) with the members of the narrower selection of the same rows (vals_sel, idx_sel: N x k, both
+    from topk over one matrix) replaced by -1, the inactive-slot mark: the multi-top-k branch
+    (sparse_coder.py:256-262) decodes only the rows the main decode has not summed."""
+    _req(vals_wide, "vals_wide", ndim=2)
+    _req(idx_wide, "idx_wide", torch.int64, 2)
+    _req(vals_sel, "vals_sel", vals_wide.dtype, 2)
+    _req(idx_sel, "idx_sel", torch.int64, 2)
+    N, kw = idx_wide.shape
+    k = idx_sel.shape[1]
+    if vals_wide.shape != idx_wide.shape or vals_sel.shape != idx_sel.shape or idx_sel.shape[0] != N or k > kw:
+        raise ValueError(f"exclude_selected: shapes {tuple(vals_wide.shape)} {tuple(idx_wide.shape)} "
+                         f"{tuple(vals_sel.shape)} {tuple(idx_sel.shape)} do not match")
+    out = torch.empty_like(idx_wide)
+    if N == 0:
+        return out
+    check(_lib.load().sphip_exclude_selected(vals_wide.data_ptr(), idx_wide.data_ptr(), kw, vals_sel.data_ptr(),
+                                            idx_sel.data_ptr(), k, _dt(vals_wide), N, out.data_ptr(), _stream(idx_wide)),
+          "sphip_exclude_selected")
+    return out
+
+
 LAZY_CAP = 4096          # chunks (8 latents each) a token's candidate list can hold (csrc/lazy.hip)
 LAZY_MAX_K = 256
 

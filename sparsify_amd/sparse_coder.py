@@ -266,7 +266,7 @@ class SparseCoder(nn.Module):
         if y is None:
             y = x
 
-        sae_out = self.decode(top_acts, top_indices)
+        sae_out = decoded = self.decode(top_acts, top_indices)
         if self.W_skip is not None:
             from .fused_encoder import _autocast_bf16
             skip = SkipProduct.apply(x, self.W_skip, _autocast_bf16())
@@ -305,10 +305,22 @@ class SparseCoder(nn.Module):
 
         if self.cfg.multi_topk:
             pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
-            top_acts, top_indices = ops.topk(pre2, 4 * self.cfg.k)                    # :257
-            top_acts = top_acts.reshape(*x.shape[:-1], -1)
-            top_indices = top_indices.reshape(*x.shape[:-1], -1)
-            sae_out = self.decode(top_acts, top_indices)
+            acts4, idx4 = ops.topk(pre2, 4 * self.cfg.k)                              # :257
+            top_acts4 = acts4.reshape(*x.shape[:-1], -1)
+            top_indices4 = idx4.reshape(*x.shape[:-1], -1)
+            if self.cfg.activation == "topk" and acts4.dtype == top_acts.dtype and self.W_dec is not None:
+                # the 4k set holds the top-k set (one selection rule, one matrix), whose rows `decoded` has summed:
+                # the forward gathers the other 3k rows only and adds. The backward is the whole 4k list's -- its
+                # W_dec gradient weighs every row with this branch's own residual, and nothing of it may reach the
+                # encoder through top_acts (the reference drops the gradient of pre_acts, fused_encoder.py:53)
+                rest = ops.exclude_selected(acts4, idx4, top_acts.reshape(-1, top_acts.shape[-1]).contiguous(),
+                                            top_indices.reshape(-1, top_indices.shape[-1]).contiguous())
+                keep_bf16 = acts4.dtype == torch.bfloat16 and self.W_dec.dtype == torch.float32
+                sae_out = SparseDecode.apply(idx4, self.W_dec, acts4 if keep_bf16 else acts4.to(self.dtype), self.b_dec,
+                                             (rest, decoded)).reshape(decoded.shape)
+            else:
+                sae_out = self.decode(top_acts4, top_indices4)
+            top_acts, top_indices = top_acts4, top_indices4
             multi_topk_fvu, _ = ResidualLoss.apply(sae_out, y, total_variance)         # :260
         else:
             multi_topk_fvu = sae_out.new_zeros(())

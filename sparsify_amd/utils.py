@@ -13,7 +13,11 @@ class SparseDecode(torch.autograd.Function):
     """Counterpart of xFormersEmbeddingBag (sparsify/xformers.py:188-209)."""
 
     @staticmethod
-    def forward(ctx, indices: Tensor, weight: Tensor, per_sample_weights: Tensor, bias: Tensor | None = None):
+    def forward(ctx, indices: Tensor, weight: Tensor, per_sample_weights: Tensor, bias: Tensor | None = None,
+                summed: tuple[Tensor, Tensor] | None = None):
+        """summed = (rest, base), multi-top-k only (sparse_coder.py:256-262): `base` (N, D) already holds the bias and
+        the rows of those slots that `rest` (= indices with these slots set to -1, ops.exclude_selected) leaves out,
+        so only the others are gathered. The backward is that of the whole list either way."""
         ops.forget_segments(indices)
         parallel.wait_for(weight)                  # an overlapped optimizer update (sign_sgd.py)
         w = weight.detach()
@@ -24,8 +28,13 @@ class SparseDecode(torch.autograd.Function):
             ctx.has_bias = bias is not None
             ctx.set_materialize_grads(False)
             return torch.empty(0, w.shape[1], dtype=torch.float32, device=w.device)
-        out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
-                                       None if bias is None else bias.detach(), table_owner=weight)
+        if summed is not None:
+            rest, base = summed
+            out = ops.add(ops.gather_rows_weighted(rest, per_sample_weights.detach().contiguous(), w, None,
+                                                   table_owner=weight), base.detach().reshape(-1, w.shape[1]).contiguous())
+        else:
+            out = ops.gather_rows_weighted(indices, per_sample_weights.detach().contiguous(), w,
+                                           None if bias is None else bias.detach(), table_owner=weight)
         ctx.save_for_backward(indices, weight, per_sample_weights)
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)
@@ -35,12 +44,12 @@ class SparseDecode(torch.autograd.Function):
     def backward(ctx, gradient):
         indices, weight, psw = ctx.saved_tensors
         if gradient is None:
-            return None, None, None, None
+            return None, None, None, None, None
         if ctx.empty:
             need = ctx.needs_input_grad
             return (None, torch.zeros_like(weight) if need[1] else None, torch.zeros_like(psw) if need[2] else None,
                     torch.zeros(weight.shape[1], dtype=torch.float32, device=weight.device)
-                    if ctx.has_bias and need[3] else None)
+                    if ctx.has_bias and need[3] else None, None)
         g = gradient.contiguous()
         if g.dtype != torch.float32:
             g = g.float()
@@ -57,7 +66,7 @@ class SparseDecode(torch.autograd.Function):
                 dead_decode.claim_pending_rows(weight, gW)     # AuxK rows of this backward pass (dead_decode.py)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gB = ops.colsum(g)
-        return None, gW, gA, gB
+        return None, gW, gA, gB, None
 
 
 def hip_decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor) -> Tensor:

@@ -165,6 +165,39 @@ def test_topk_ties_and_degenerate_rows(device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,k,mult", [(8192, 64, 4), (1000, 17, 4), (5000, 1100, 4), (4096, 300, 2), (640, 160, 4), (64, 7, 1)])
+def test_exclude_selected_splits_a_wider_topk(device, dtype, M, k, mult):
+    """sphip_exclude_selected (multi-top-k, sparse_coder.py:256-262): the top-k set is a subset of the top-(mult k)
+    set of the same row by the selection rule (ties to the lowest index); exactly its members are marked -1,
+    whatever the order either kernel path emitted (value order, or index order on the exact path), ties included."""
+    from sparsify_amd import ops
+    g = torch.Generator().manual_seed(M + k)
+    rows = [torch.randn(9, M, generator=g), torch.randn(9, M, generator=g).clamp_min(0),
+            torch.randint(0, 4, (9, M), generator=g).float(),                        # ties at the boundary of both
+            torch.randn(9, M, generator=g).clamp_min(0) * (torch.rand(9, M, generator=g) < 0.02),   # mostly zeros
+            torch.zeros(2, M), torch.full((2, M), 2.5)]
+    pre = dev(torch.cat(rows).to(dtype))
+    kw = mult * k
+    v, i = ops.topk(pre, k)
+    vw, iw = ops.topk(pre, kw)
+    rest = ops.exclude_selected(vw, iw, v, i).cpu()
+    i, iw = i.cpu(), iw.cpu()
+    marked = rest == -1
+    assert torch.equal(marked.sum(1), torch.full((pre.shape[0],), k))
+    assert torch.equal(rest[~marked], iw[~marked])
+    for n in range(pre.shape[0]):
+        assert set(iw[n][marked[n]].tolist()) == set(i[n].tolist()), n
+    # an inactive slot of the wider list stays as it is, one of the narrower list selects nothing
+    iw2 = iw.clone()
+    iw2[:, -1] = -1
+    i2 = i.clone()
+    i2[:, 0] = -1
+    rest2 = ops.exclude_selected(vw, dev(iw2), v, dev(i2)).cpu()
+    assert bool((rest2[:, -1] == -1).all())
+    assert bool(((rest2 == -1).sum(1) <= k + 1).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,k", [(13120, 2048), (16384, 1024), (8192, 512), (4096, 2048), (2056, 300), (8, 8)])
 def test_topk_register_resident_exact_path(device, monkeypatch, dtype, M, k):
     """Short rows with a large k (the compact AuxK selection) take topk_resident_kernel when the row
