@@ -1,6 +1,7 @@
 """Random shapes through sphip_topk (all its paths: four-wave block-maxima, 1024-thread sweeps, exact
 bisection, register-resident exact) against torch.topk: the selected values must be the k largest and
-the indices must point at them. run(seconds, max_cases) is also what tests/test_hip_fuzz.py
+the indices must point at them; and a wider selection of the same row, through sphip_exclude_selected,
+must mark exactly the members of the narrower one. run(seconds, max_cases) is also what tests/test_hip_fuzz.py
 calls for a bounded, seeded slice. Usage: python benchmarks/topk_fuzz.py [seconds]"""
 import os
 import random
@@ -43,11 +44,19 @@ def run(budget: float = 60.0, max_cases: int | None = None) -> int:
             pad[:N, :M] = pre.float()
             tm = pad.reshape(-1, 64, T, 128).amax(-1).permute(0, 2, 1).contiguous().to(dtype).to(dev)
         vals, idx = ops.topk(d, k, tile_max=tm)
+        kw = min(M, rng.choice([2, 4]) * k)
+        wider_ok = True
+        if kw > k:
+            # the wider selection of the same row holds the narrower one: exclude_selected marks exactly its members
+            vw, iw = ops.topk(d, kw, tile_max=tm if rng.random() < 0.5 else None)
+            marked = ops.exclude_selected(vw, iw, vals, idx).cpu() == -1
+            wider_ok = bool((marked.sum(1) == k).all()) and torch.equal(
+                iw.cpu()[marked].reshape(N, k).sort(-1).values, idx.cpu().sort(-1).values)
         vals, idx = vals.cpu(), idx.cpu()
         ref = pre.float().topk(k, dim=-1).values
         ok = (torch.equal(vals.float().sort(-1, descending=True).values, ref) and torch.equal(pre.float().gather(1, idx), vals.float())
               and int(idx.min()) >= 0 and int(idx.max()) < M and bool((idx.sort(-1).values.diff(dim=-1) > 0).all() if k > 1 else True))
-        if not ok:
+        if not (ok and wider_ok):
             raise AssertionError(f"MISMATCH dtype={dtype} N={N} M={M} k={k} kind={kind} tile_max={tm is not None} case={n}")
         n += 1
     print(f"{n} random cases in {time.time() - t0:.0f} s: all selections exact", flush=True)
