@@ -241,6 +241,7 @@ def main():
         torch.cuda.empty_cache()
         for kind in ("auxk", "multitopk", "signum", "skewed"):
             variants[kind] = variant_run(kind, N, D, M, k, device)
+        variants["batch65536"] = variant_run("batch65536", 65536, D, M, k, device, steps=3, warm=1)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -317,6 +318,11 @@ def main():
                                      "unpinned); the headline runs plain SignSGD, which is pinned to sign_sgd.py",
                       "skewed_ms_per_step": variants.get("skewed", {}).get("ms_per_step"),
                       "skewed_usage": variants.get("skewed", {}).get("usage"),
+                      "batch65536_ms_per_step": variants.get("batch65536", {}).get("ms_per_step"),
+                      "batch65536_tokens_per_s": (65536e3 / variants["batch65536"]["ms_per_step"]
+                                                  if "batch65536" in variants else None),
+                      "batch65536_note": "the same step on 65536 tokens (the reference's default batch: 32 sequences of "
+                                         "2048 tokens); the weight gradients take the batch in token blocks",
                       "skewed_note": "heavy-tailed latent usage (power-law atoms, coder planted with the dictionary) "
                                      "instead of the flat usage of Gaussian rows; same step otherwise"},
         }
@@ -334,6 +340,7 @@ def variant_run(kind: str, N, D, M, k, device, steps: int = 4, warm: int = 2) ->
                 k_aux = d_in / 2 (the second run SURVEY.md 8d asks for)
       multitopk the multi-top-k term (sparse_coder.py:256-262): a second decode over the 4k best latents
       signum    the reference's default optimizer: schedule-free SignSGD (trainer.py:146-162; parity unpinned)
+      batch65536 the plain step on N = 65536 tokens, the reference's default batch (config.py: batch_size 32 x ctx 2048)
       skewed    heavy-tailed latent usage instead of Gaussian rows' flat one: SyntheticActivations(skew="zipf"),
                 the coder planted with the dictionary (trainer.py here); reports the usage histogram too"""
     from sparsify_amd import SparseCoderConfig, TrainConfig

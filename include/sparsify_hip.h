@@ -218,6 +218,18 @@ int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, 
                                 float* gW, float* gbias, float* dcoeff, const float* row_shift,
                                 int64_t N, int64_t k, int64_t M, int64_t D, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* The same for a batch taken in token blocks (the reference's index_add_ / atomics accumulate over
+ * any number of rows, fused_encoder.py:67-84, xformers.py:110-136; here a block's N x 128 B row
+ * slices have to fit an XCD's L2, i.e. N <= 24576): call once per block of tokens with that block's
+ * segments, coeff, rows and dcoeff; accumulate = 0 writes gW / gbias, != 0 adds the block's sums to
+ * what an earlier call left there (fixed order: block after block). Built into the L2-sliced kernels
+ * only: SPHIP_EUNSUPPORTED with accumulate != 0 for a shape that takes another form (nothing has
+ * been added then; the caller sums the blocks' outputs itself). */
+int sphip_segmented_weight_grad_acc(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                    int coeff_dtype, const void* rows, int rows_dtype, const float* W,
+                                    float* gW, float* gbias, float* dcoeff, const float* row_shift,
+                                    int64_t N, int64_t k, int64_t M, int64_t D, void* workspace,
+                                    size_t workspace_bytes, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------- loss (FVU / AuxK) */
 

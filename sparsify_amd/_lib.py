@@ -17,6 +17,9 @@ ABI_VERSION = 3
 F32, BF16 = 0, 1
 
 
+SPHIP_EUNSUPPORTED = 2        # include/sparsify_hip.h
+
+
 class HipLibraryError(RuntimeError):
     """An entry point of libsparsify_hip.so returned a non-zero status."""
 
@@ -49,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_build_latent_segments": (_I, [_P, _L, _L, _L, _P, _P, _P, _Z, _P]),
     "sphip_weight_grad_workspace_bytes": (_Z, [_L, _L, _L]),
     "sphip_segmented_weight_grad": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P]),
+    "sphip_segmented_weight_grad_acc": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _I, _P]),
     "sphip_reduce_workspace_bytes": (_Z, [_L, _L]),
     "sphip_total_variance": (_I, [_P, _I, _L, _L, _P, _P, _Z, _P]),
     "sphip_total_variance_static": (_I, [_P, _I, _L, _L, _P, _P]),
@@ -123,4 +127,6 @@ def load() -> ctypes.CDLL:
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().sphip_last_error().decode(errors="replace")
-        raise HipLibraryError(f"{what} failed (status {status}): {msg}")
+        err = HipLibraryError(f"{what} failed (status {status}): {msg}")
+        err.status = status
+        raise err

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
                                                                float* __restrict__ slab = nullptr, int64_t E = 0,
                                                                SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f},
                                                                const float* __restrict__ gb_in = nullptr,
-                                                               float* __restrict__ bpart = nullptr) {
+                                                               float* __restrict__ bpart = nullptr, int accum = 0) {
     constexpr int C = Piece<RT>::COLS;
     constexpr int SLICE_COLS = 8 * C;
     // a workgroup holds 32 latents for as long as its longest segment lasts: with `skew` set,
@@ -562,9 +562,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
                 }
             }
         } else {
+            // accum (kernel argument: uniform): the rows of an earlier token block are already there
+            // (sphip_segmented_weight_grad_acc) -- block sums added in block order
+            f4 prev[C / 4];
+            if (accum) {
+#pragma unroll
+                for (int c = 0; c < C; c += 4) prev[c / 4] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(o + c));
+            }
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
                 f4 t = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+                if (accum) t += prev[c / 4];
                 __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o + c));
             }
         }
@@ -612,7 +620,7 @@ template <typename CT>
 __global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __restrict__ perm,
                                                             const int* __restrict__ seg_begin,
                                                             const CT* __restrict__ coeff, int M,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int accum = 0) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int beg = 0, end = 0;
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __re
             t += c0, t += c1, t += c2, t += c3;
         }
         for (; p < end; ++p) t += Elem<CT>::load(coeff, perm[p]);
-        out[j] = t;
+        out[j] = accum ? out[j] + t : t;
     }
     unsigned long long todo = __ballot(is_long);
     while (todo != 0) {                                     // wave-uniform
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(256) void seg_coeff_sum_kernel(const uint32_t* __re
         float t = 0.f;
         for (int p = b + lane; p < e; p += 64) t += Elem<CT>::load(coeff, perm[p]);
         t = wave_sum(t);
-        if (lane == 0) out[j + src] = t;                    // lane 0's latent is the wave's first
+        if (lane == 0) out[j + src] = accum ? out[j + src] + t : t;    // lane 0's latent is the wave's first
     }
 }
 
@@ -971,7 +979,7 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(const int* __rest
                                                                const float* __restrict__ pbsum,
                                                                const float* __restrict__ row_shift,
                                                                float* __restrict__ gW, int D, float lr,
-                                                               bf16_t* __restrict__ shadow, SfArgs sf) {
+                                                               bf16_t* __restrict__ shadow, SfArgs sf, int accum = 0) {
     const int n_long = min(hdr[0], cap);
     for (int i = blockIdx.x; i < n_long; i += gridDim.x) {
         const int2 t = list[i];
@@ -1014,6 +1022,10 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(const int* __rest
                     *reinterpret_cast<uint2*>(shadow + (int64_t)j * D + col) = make_uint2(lo, hi);
                 }
             } else {
+                if (accum) {                                 // an earlier token block's row is already there
+                    const float4 o4 = *reinterpret_cast<const float4*>(gW + (int64_t)j * D + col);
+                    acc.x += o4.x, acc.y += o4.y, acc.z += o4.z, acc.w += o4.w;
+                }
                 *reinterpret_cast<float4*>(gW + (int64_t)j * D + col) = acc;
             }
         }
@@ -1062,7 +1074,8 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
                           float* gbias, const float* row_shift, int64_t N, int k, int M, int D, hipStream_t s,
                           float lr = 0.f, bf16_t* shadow = nullptr, const int* skew = nullptr,
                           const float* Wdot = nullptr, float* slab = nullptr, SfArgs sf = SfArgs{nullptr, 0.f, 0.f, 0.f},
-                          const float* gb_in = nullptr, float* bpart = nullptr, const unsigned* packed4 = nullptr) {
+                          const float* gb_in = nullptr, float* bpart = nullptr, const unsigned* packed4 = nullptr,
+                          int accum = 0) {
     constexpr int C = Piece<RT>::COLS;
     if (D % C != 0) return false;
     const int num_slices = (int)cdiv(D, 8 * C);
@@ -1080,20 +1093,20 @@ static bool launch_sliced(const uint2* packed, const int* seg, const void* rows,
         hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, FUSE, true>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            reinterpret_cast<const uint2*>(packed4), seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart, accum);
     else if (packed4 != nullptr)
         hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            reinterpret_cast<const uint2*>(packed4), seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart, accum);
     else if (FUSE && sf.z != nullptr)
         hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, FUSE>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart, accum);
     else
         hipLaunchKernelGGL((seg_wgrad_sliced_kernel<RT, FUSE, DOT, false>), dim3((unsigned)nblocks), dim3(256), 0, s, packed, seg,
                            (const RT*)rows_sm, gW, gbias, row_shift, make_fastdiv((unsigned)k), N, M, D, bps, num_slices, lr,
-                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart);
+                           shadow, skew, SKEW_T, Wdot, slab, (int64_t)N * k, sf, gb_in, bpart, accum);
     return true;
 }
 
@@ -1181,7 +1194,8 @@ template <typename RT, bool DOT, bool FUSE>
 static void reduce_long_latents(const LongTail& t, const uint2* packed, const unsigned* packed4, const int* seg_begin,
                                 const void* rows_sm, const float* W, float* gW, float* slab, const float* row_shift,
                                 int64_t N, int64_t k, int64_t D, hipStream_t s, float lr = 0.f,
-                                sphip::bf16_t* shadow = nullptr, sphip::SfArgs sf = sphip::SfArgs{nullptr, 0.f, 0.f, 0.f}) {
+                                sphip::bf16_t* shadow = nullptr, sphip::SfArgs sf = sphip::SfArgs{nullptr, 0.f, 0.f, 0.f},
+                                int accum = 0) {
     using namespace sphip;
     const int num_slices = (int)cdiv(D, 8 * Piece<RT>::COLS);
     const FastDiv kd = make_fastdiv((unsigned)k);
@@ -1193,7 +1207,7 @@ static void reduce_long_latents(const LongTail& t, const uint2* packed, const un
         hipLaunchKernelGGL((seg_long_chunk_kernel<RT, DOT, false>), grid, block, 0, s, (const void*)packed, seg_begin,
                            (const RT*)rows_sm, W, slab, kd, N, N * k, (int)D, num_slices, t.hdr, t.ctab, t.chunk_cap, t.prow, t.pbsum);
     hipLaunchKernelGGL((seg_long_combine_kernel<FUSE>), dim3(256), block, 0, s, t.hdr, t.list, t.cap, seg_begin, t.prow,
-                       t.pbsum, row_shift, gW, (int)D, lr, shadow, sf);
+                       t.pbsum, row_shift, gW, (int)D, lr, shadow, sf, accum);
 }
 
 extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_t D) {
@@ -1208,13 +1222,13 @@ extern "C" size_t sphip_weight_grad_workspace_bytes(int64_t N, int64_t k, int64_
 }
 
 static int launch_coeff_sums(const uint32_t* perm, const int32_t* seg_begin, const void* coeff, int coeff_dtype, int64_t M,
-                             float* out, hipStream_t s) {
+                             float* out, hipStream_t s, int accum = 0) {
     using namespace sphip;
     dim3 grid((unsigned)cdiv(M, 256)), block(256);
     if (coeff_dtype == SPHIP_F32)
-        hipLaunchKernelGGL((seg_coeff_sum_kernel<float>), grid, block, 0, s, perm, seg_begin, (const float*)coeff, (int)M, out);
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<float>), grid, block, 0, s, perm, seg_begin, (const float*)coeff, (int)M, out, accum);
     else
-        hipLaunchKernelGGL((seg_coeff_sum_kernel<bf16_t>), grid, block, 0, s, perm, seg_begin, (const bf16_t*)coeff, (int)M, out);
+        hipLaunchKernelGGL((seg_coeff_sum_kernel<bf16_t>), grid, block, 0, s, perm, seg_begin, (const bf16_t*)coeff, (int)M, out, accum);
     SPHIP_CHECK_LAUNCH("segment_coeff_sums");
     return SPHIP_OK;
 }
@@ -1223,7 +1237,7 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
                             int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                             float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
                             int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
-                            void* stream);
+                            void* stream, int accum = 0);
 
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
@@ -1237,11 +1251,23 @@ extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* 
     return launch_coeff_sums(perm, seg_begin, coeff, coeff_dtype, M, gbias, (hipStream_t)stream);
 }
 
+extern "C" int sphip_segmented_weight_grad_acc(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
+                                               int coeff_dtype, const void* rows, int rows_dtype, const float* W,
+                                               float* gW, float* gbias, float* dcoeff, const float* row_shift,
+                                               int64_t N, int64_t k, int64_t M, int64_t D, void* workspace,
+                                               size_t workspace_bytes, int accumulate, void* stream) {
+    const int acc = accumulate != 0;
+    const int rc = weight_grad_impl(perm, seg_begin, coeff, coeff_dtype, rows, rows_dtype, W, gW, nullptr, dcoeff, row_shift,
+                                    N, k, M, D, workspace, workspace_bytes, stream, acc);
+    if (rc != SPHIP_OK || gbias == nullptr) return rc;
+    return launch_coeff_sums(perm, seg_begin, coeff, coeff_dtype, M, gbias, (hipStream_t)stream, acc);
+}
+
 static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                             int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                             float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
                             int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            void* stream, int accum) {
     using namespace sphip;
     SPHIP_REQUIRE(valid_dtype(coeff_dtype) && valid_dtype(rows_dtype), SPHIP_EINVAL, "segmented_weight_grad: bad dtype");
     SPHIP_REQUIRE(perm && seg_begin && coeff && rows && gW, SPHIP_EINVAL, "segmented_weight_grad: null pointer");
@@ -1283,9 +1309,6 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
         ((force && force[0] == 'l') || (!force && big && N * k >= 4 * M && N * 128 <= (3ll << 20)))) {
         float* slab = (float*)((char*)rows_sm + ((rows_sm_bytes(N, D) + 255) & ~(size_t)255));
         // latents with more than SKEW_T entries (dense latents: a workgroup of the sliced kernel
-        // lives as long as its longest segment) are listed on the device and left to the
-        // wave-per-latent wide kernel, launched next to the sliced one with a small fixed grid
-        // latents with more than SKEW_T entries (dense latents: a workgroup of the sliced kernel
         // lives as long as its longest segment) are listed on the device and left to the chunked
         // long-segment kernels, launched next to the sliced one with small fixed grids
         const bool use_long = wide_eligible(D);
@@ -1295,15 +1318,22 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
             SPHIP_REQUIRE(list_long_latents(lt, seg_begin, M, s), SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
         if (launch_sliced<float, false, true>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M,
                                               (int)D, s, 0.f, nullptr, skew, W, slab, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr,
-                                              nullptr, packed4)) {
+                                              nullptr, packed4, accum)) {
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(l2 dot)");
             if (use_long)
-                reduce_long_latents<float, true, false>(lt, packed, packed4, seg_begin, rows_sm, W, gW, slab, row_shift, N, k, D, s);
+                reduce_long_latents<float, true, false>(lt, packed, packed4, seg_begin, rows_sm, W, gW, slab, row_shift, N, k, D, s,
+                                                        0.f, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, accum);
             hipLaunchKernelGGL(seg_dcoeff_bounded_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, s, packed, slab, E, seg_begin, (int)M, (int)(D / 32), dcoeff);
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(dcoeff)");
             return SPHIP_OK;
         }
     }
+    // accumulation into rows that are already there is built into the L2-sliced forms only (the caller adds otherwise)
+    const bool sliced_nodot = !dot && !(force && (force[0] == 'f' || force[0] == 'w')) &&
+                              !(wide_eligible(D) && !(force && force[0] == 'f') && want_wide);
+    SPHIP_REQUIRE(!accum || sliced_nodot, SPHIP_EUNSUPPORTED,
+                  "segmented_weight_grad_acc: this shape does not take an L2-sliced kernel (N=%lld k=%lld M=%lld D=%lld)",
+                  (long long)N, (long long)k, (long long)M, (long long)D);
     if (wide_eligible(D) && !(force && force[0] == 'f') && want_wide) {
         float* slab = (float*)rows_sm;
         const FastDiv kd = make_fastdiv((unsigned)k);
@@ -1332,19 +1362,22 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
         if (use_long)
             SPHIP_REQUIRE(list_long_latents(lt, seg_begin, M, s), SPHIP_ELAUNCH, "segmented_weight_grad: memset failed");
         const bool done = rows_dtype == SPHIP_F32
-                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4)
-                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4);
+                              ? launch_sliced<float>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4, accum)
+                              : launch_sliced<bf16_t>(packed, seg_begin, rows, rows_sm, gW, gbias, row_shift, N, (int)k, (int)M, (int)D, s, 0.f, nullptr, skew, nullptr, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, nullptr, nullptr, packed4, accum);
         if (done) {
             if (use_long) {
                 if (rows_dtype == SPHIP_F32)
-                    reduce_long_latents<float, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s);
+                    reduce_long_latents<float, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s,
+                                                             0.f, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, accum);
                 else
-                    reduce_long_latents<bf16_t, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s);
+                    reduce_long_latents<bf16_t, false, false>(lt, packed, packed4, seg_begin, rows_sm, nullptr, gW, nullptr, row_shift, N, k, D, s,
+                                                              0.f, nullptr, SfArgs{nullptr, 0.f, 0.f, 0.f}, accum);
             }
             SPHIP_CHECK_LAUNCH("segmented_weight_grad(sliced)");
             return SPHIP_OK;
         }
     }
+    SPHIP_REQUIRE(!accum, SPHIP_EUNSUPPORTED, "segmented_weight_grad_acc: the L2-sliced kernel does not take D=%lld", (long long)D);
     if (rows_dtype == SPHIP_F32) {
         if (dot) launch_nv<float, true>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);
         else launch_nv<float, false>(packed, seg_begin, rows, W, gW, gbias, dcoeff, row_shift, (int)k, (int)M, (int)D, s);

@@ -437,10 +437,14 @@ def build_latent_segments(idx: Tensor, M: int) -> LatentSegments:
 _segment_cache: dict[int, tuple] = {}
 
 
+_block_segment_cache: dict[int, tuple] = {}     # the same per token block (weight_grad_in_token_blocks)
+
+
 def forget_segments(idx: Tensor) -> None:
     """Called by every forward that takes `idx`: drops a stale entry left by an earlier
     tensor that lived at the same address."""
     _segment_cache.pop(idx.data_ptr(), None)
+    _block_segment_cache.pop(idx.data_ptr(), None)
 
 
 def cached_segments(idx: Tensor, M: int) -> LatentSegments:
@@ -461,8 +465,12 @@ def cached_segments(idx: Tensor, M: int) -> LatentSegments:
 
 
 def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: Tensor | None = None,
-                          want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None):
-    """(gW, gbias, dcoeff); xformers.py:88-136 and fused_encoder.py:67-84."""
+                          want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None,
+                          into: tuple | None = None, dcoeff_out: Tensor | None = None):
+    """(gW, gbias, dcoeff); xformers.py:88-136 and fused_encoder.py:67-84.
+    into = (gW, gbias or None): add this call's sums to those tensors instead of returning new ones (a batch taken in
+    token blocks, weight_grad_in_token_blocks); raises HipLibraryError (status SPHIP_EUNSUPPORTED) where the kernel form the shape
+    takes cannot. dcoeff_out: where to write dcoeff (a block's rows of the whole batch's tensor)."""
     _req(coeff, "coeff", ndim=2)
     _req(rows, "rows", ndim=2)
     N, k, M = seg.N, seg.k, seg.M
@@ -479,18 +487,82 @@ def segmented_weight_grad(seg: LatentSegments, coeff: Tensor, rows: Tensor, W: T
         _req(row_shift, "row_shift", torch.float32, 1)
         if row_shift.shape[0] != D:
             raise ValueError("segmented_weight_grad: row_shift shape mismatch")
-    gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
-    gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
-    dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if want_dcoeff else None
+    if into is not None:
+        gW, gb = into
+        _req(gW, "gW", torch.float32, 2)
+        if tuple(gW.shape) != (M, D) or (want_bias and (gb is None or tuple(gb.shape) != (M,))):
+            raise ValueError("segmented_weight_grad: `into` does not match (M, D) / (M,)")
+        gb = _req(gb, "gbias", torch.float32, 1) if want_bias else None
+    else:
+        gW = torch.empty(M, D, dtype=torch.float32, device=rows.device)
+        gb = torch.empty(M, dtype=torch.float32, device=rows.device) if want_bias else None
+    dc = None
+    if want_dcoeff:
+        dc = torch.empty(N, k, dtype=torch.float32, device=rows.device) if dcoeff_out is None else dcoeff_out
+        _req(dc, "dcoeff", torch.float32, 2)
+        if tuple(dc.shape) != (N, k):
+            raise ValueError("segmented_weight_grad: dcoeff_out shape mismatch")
     lib = _lib.load()
     ws = _workspace(rows.device, lib.sphip_weight_grad_workspace_bytes(N, k, D), "wgrad")
     _ev = timer.start("sphip_segmented_weight_grad", rows)
-    check(lib.sphip_segmented_weight_grad(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
-                                                 _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
-                                                 gW.data_ptr(), _ptr(gb), _ptr(dc), _ptr(row_shift), N, k, M, D, ws.data_ptr(), ws.numel(),
-                                         _stream(rows)),
-          "sphip_segmented_weight_grad")
-    timer.stop(_ev, rows)
+    try:
+        check(lib.sphip_segmented_weight_grad_acc(seg.perm.data_ptr(), seg.seg_begin.data_ptr(), coeff.data_ptr(),
+                                                  _dt(coeff), rows.data_ptr(), _dt(rows), _ptr(W) if want_dcoeff else None,
+                                                  gW.data_ptr(), _ptr(gb), _ptr(dc), _ptr(row_shift), N, k, M, D,
+                                                  ws.data_ptr(), ws.numel(), int(into is not None), _stream(rows)),
+              "sphip_segmented_weight_grad_acc")
+    finally:
+        timer.stop(_ev, rows)
+    return gW, gb, dc
+
+
+# a block's N x 128 B slices of the rows have to fit an XCD's 4 MiB L2 next to the streams that pass through
+TOKEN_BLOCK_LIMIT = 24576
+TOKEN_BLOCK = 16384
+
+
+def token_blocks(N: int) -> list[tuple[int, int]]:
+    """[(lo, hi)]: N tokens cut into nearly equal blocks of at most TOKEN_BLOCK (multiples of 64 but the last)."""
+    nb = -(-N // TOKEN_BLOCK)
+    step = -(-(-(-N // nb)) // 64) * 64
+    return [(lo, min(lo + step, N)) for lo in range(0, N, step)]
+
+
+def weight_grad_in_token_blocks(indices: Tensor, M: int, coeff: Tensor, rows: Tensor, W: Tensor | None = None,
+                                want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None):
+    """segmented_weight_grad over the whole batch, (gW, gbias, dcoeff), for batches whose row slices do not fit the
+    L2-sliced kernels at once (N > TOKEN_BLOCK_LIMIT: the reference's default step is 32 x 2048 = 65536 tokens):
+    blocks of <= TOKEN_BLOCK tokens, each with its own segments, the later ones adding their sums to the first one's
+    (block after block: a fixed order). Where the shape takes a kernel form that cannot add, the whole batch goes
+    through one call as before."""
+    N = indices.shape[0]
+    blocks = token_blocks(N)
+    # decoder and encoder backward share the index tensor: the blocks' segments are sorted once per step, under
+    # the same rules as cached_segments (made in backward, dropped by the next forward that sees the address)
+    stamp = (indices._version, tuple(indices.shape), M, tuple(blocks))
+    hit = _block_segment_cache.get(indices.data_ptr())
+    if hit is None or hit[0] != stamp:
+        if len(_block_segment_cache) > 4:
+            _block_segment_cache.clear()
+        hit = (stamp, [build_latent_segments(indices[lo:hi], M) for lo, hi in blocks])
+        _block_segment_cache[indices.data_ptr()] = hit
+    gW = gb = None
+    dc = torch.empty(N, coeff.shape[1], dtype=torch.float32, device=rows.device) if want_dcoeff else None
+    for b, (lo, hi) in enumerate(blocks):
+        seg = hit[1][b]
+        args = (seg, coeff[lo:hi], rows[lo:hi], W)
+        kw = dict(want_bias=want_bias, want_dcoeff=want_dcoeff, row_shift=row_shift,
+                  dcoeff_out=None if dc is None else dc[lo:hi])
+        if b == 0:
+            gW, gb, _ = segmented_weight_grad(*args, **kw)
+            continue
+        try:
+            segmented_weight_grad(*args, into=(gW, gb), **kw)
+        except _lib.HipLibraryError as err:
+            if b != 1 or getattr(err, "status", None) != _lib.SPHIP_EUNSUPPORTED:
+                raise
+            return segmented_weight_grad(build_latent_segments(indices, M), coeff, rows, W, want_bias=want_bias,
+                                         want_dcoeff=want_dcoeff, row_shift=row_shift)
     return gW, gb, dc
 
 

@@ -56,9 +56,14 @@ class SparseDecode(torch.autograd.Function):
         need_w, need_a = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gW = gA = gB = None
         if need_w or need_a:
-            seg = ops.cached_segments(indices, weight.shape[0])
-            gW, _, gA = ops.segmented_weight_grad(seg, psw.detach().contiguous(), g, weight.detach(),
-                                                  want_dcoeff=need_a)
+            if indices.shape[0] > ops.TOKEN_BLOCK_LIMIT:
+                # more tokens than the L2-sliced kernels take at once (the reference's default step: 65536)
+                gW, _, gA = ops.weight_grad_in_token_blocks(indices, weight.shape[0], psw.detach().contiguous(), g,
+                                                            weight.detach(), want_dcoeff=need_a)
+            else:
+                seg = ops.cached_segments(indices, weight.shape[0])
+                gW, _, gA = ops.segmented_weight_grad(seg, psw.detach().contiguous(), g, weight.detach(),
+                                                      want_dcoeff=need_a)
             if gA is not None and gA.dtype != psw.dtype:
                 gA = gA.to(psw.dtype)
             if need_w:

@@ -177,3 +177,43 @@ def test_config1_pythia160m_shape_all_layers(device):
         want = float(O.train_step_signsgd(P, acts, None, ocfg, lr, step=s, bf16=True)["fvu"])
         tol = 2e-3 if s == 0 else 5e-2          # bf16 tie picks decorrelate the runs slowly
         assert abs(curves[follow][s] - want) <= tol * want, (s, curves[follow][s], want)
+
+
+def test_step_on_more_tokens_than_one_block_vs_oracle(device):
+    """N = 26000 tokens in one step: more than the L2-sliced weight-gradient kernels take at once (24576), so both
+    backward passes go through ops.weight_grad_in_token_blocks (two blocks, the second adding to the first). The
+    reference's index_add_ / atomics take any number of rows (fused_encoder.py:67-84, xformers.py:110-136; its
+    default step is 65536 tokens); forward, losses and every gradient against the oracle on the same selection."""
+    from oracle import sae_oracle as O
+    from sparsify_amd import SparseCoder, SparseCoderConfig, ops
+    from test_hip_api import run_coder, same_topk_sets
+    N, D, M, k = 26000, 512, 2048, 16
+    assert N > ops.TOKEN_BLOCK_LIMIT and len(ops.token_blocks(N)) == 2
+    torch.manual_seed(0)
+    sae = SparseCoder(D, SparseCoderConfig(num_latents=M, k=k)).cuda()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(N, D, generator=g) + torch.randn(D, generator=g)).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        sae.b_dec.copy_(x.float().mean(0))
+    P = {"W_enc": sae.encoder.weight.detach().cpu().clone(), "b_enc": sae.encoder.bias.detach().cpu().clone(),
+         "W_dec": sae.W_dec.detach().cpu().clone(), "b_dec": sae.b_dec.detach().cpu().clone()}
+    ops.timer.enabled = True
+    ops.timer.reset()
+    try:
+        out = run_coder(sae, "bf16", x, None, None)
+        out.fvu.backward()
+        torch.cuda.synchronize()
+        calls = ops.timer.summary()
+    finally:
+        ops.timer.enabled = False
+    assert calls["sphip_segmented_weight_grad"]["calls"] == 4           # two blocks x (W_dec, encoder.weight)
+    assert calls["sphip_build_latent_segments"]["calls"] == 2           # sorted once per block, shared by the two
+    forced = {"top": (out.latent_acts.detach().cpu(), out.latent_indices.cpu())}
+    ref, G = O.forward_backward(P, x.cpu(), None, O.OracleConfig(k=k), bf16=True, forced=forced)
+    same_topk_sets(out.latent_indices.cpu(), O.select_latents(ref["pre_acts"], k, "topk")[1], ref["pre_acts"], k, margin=2**-7)
+    torch.testing.assert_close(out.sae_out.detach().cpu(), ref["sae_out"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(float(out.fvu.detach()), float(ref["fvu"]), rtol=2e-4, atol=1e-6)
+    grads = {"W_enc": sae.encoder.weight.grad, "b_enc": sae.encoder.bias.grad, "W_dec": sae.W_dec.grad, "b_dec": sae.b_dec.grad}
+    for pname, gr in grads.items():
+        rel = (gr.cpu() - G[pname]).norm() / G[pname].norm().clamp_min(1e-12)
+        assert rel < 2e-3, f"{pname}: relative error {rel:.3e}"

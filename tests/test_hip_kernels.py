@@ -850,6 +850,83 @@ def test_weight_grad_l2_dot_path(device, monkeypatch, skewed):
         torch.testing.assert_close(dc, ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("rdtype,dot", [(torch.float32, True), (torch.float32, False), (torch.bfloat16, False)])
+@pytest.mark.parametrize("skewed", [False, True])
+def test_weight_grad_accumulates_over_token_blocks(device, rdtype, dot, skewed):
+    """sphip_segmented_weight_grad_acc: a second block of tokens adds its sums to the rows the first one wrote --
+    bit for bit the fp32 sum of the two blocks' own outputs (gW and gbias; long segments through the chunked path
+    included), dcoeff per block untouched; and ops.weight_grad_in_token_blocks over a batch too long for the
+    L2-sliced kernels (the reference's index_add_ / atomics take any number of rows, fused_encoder.py:67-84,
+    xformers.py:110-136) against a float64 sum over the whole batch."""
+    from sparsify_amd import ops
+    torch.manual_seed(5)
+    N, D, M, k = 8192, 1024, 2048, 16
+    idx = torch.stack([torch.randperm(M)[:k] for _ in range(N)])
+    if skewed:
+        idx[:, 0] = 9                                     # fires on every token: thousands of entries per block
+        idx[::5, 1] = 1200
+    idx = dev(idx)
+    coeff = dev(torch.randn(N, k).to(torch.bfloat16))
+    rows = dev(torch.randn(N, D).to(rdtype))
+    W = dev(torch.randn(M, D)) if dot else None
+    shift = None if dot else dev(torch.randn(D))
+    kw = dict(want_bias=True, want_dcoeff=dot, row_shift=shift)
+    h = N // 2
+    segs = [ops.build_latent_segments(idx[lo:hi], M) for lo, hi in ((0, h), (h, N))]
+    a = ops.segmented_weight_grad(segs[0], coeff[:h], rows[:h], W, **kw)
+    b = ops.segmented_weight_grad(segs[1], coeff[h:], rows[h:], W, **kw)
+    gW, gb = a[0].clone(), a[1].clone()
+    dc2 = torch.full((N - h, k), float("nan"), device="cuda") if dot else None
+    ops.segmented_weight_grad(segs[1], coeff[h:], rows[h:], W, into=(gW, gb), dcoeff_out=dc2, **kw)
+    assert torch.equal(gW, a[0] + b[0]) and torch.equal(gb, a[1] + b[1])
+    if dot:
+        assert torch.equal(dc2, b[2])
+    # the driver: blocks of at most TOKEN_BLOCK tokens
+    old = ops.TOKEN_BLOCK
+    ops.TOKEN_BLOCK = 3000
+    try:
+        assert ops.token_blocks(N)[-1][1] == N and all(hi - lo <= 3000 for lo, hi in ops.token_blocks(N))
+        tW, tb, tdc = ops.weight_grad_in_token_blocks(idx, M, coeff, rows, W, **kw)
+    finally:
+        ops.TOKEN_BLOCK = old
+    hit = torch.zeros(N, M, dtype=torch.float64, device="cuda")
+    hit.scatter_add_(1, idx, coeff.double())
+    want_b = hit.sum(0)
+    want_W = hit.T @ rows.double()
+    if shift is not None:
+        want_W -= want_b[:, None] * shift.double()
+    torch.testing.assert_close(tW.double(), want_W, rtol=1e-5, atol=2e-5 * float(want_W.abs().max()))
+    torch.testing.assert_close(tb.double(), want_b, rtol=1e-5, atol=1e-4)
+    if dot:
+        whole = ops.segmented_weight_grad(ops.build_latent_segments(idx, M), coeff, rows, W, **kw)
+        torch.testing.assert_close(tdc, whole[2], rtol=1e-4, atol=1e-3)
+    tW2, tb2, _ = ops.weight_grad_in_token_blocks(idx, M, coeff, rows, W, **kw)      # default blocks: one call
+    torch.testing.assert_close(tW2, tW, rtol=1e-5, atol=2e-5 * float(want_W.abs().max()))
+
+
+def test_weight_grad_token_blocks_fall_back_where_the_kernel_cannot_add(device):
+    """A shape whose dcoeff path is not the L2-sliced kernel (small rows): the accumulate call reports
+    SPHIP_EUNSUPPORTED without touching gW, and the driver runs the whole batch in one call instead."""
+    from sparsify_amd import _lib, ops
+    torch.manual_seed(6)
+    N, D, M, k = 300, 64, 200, 4
+    idx = dev(torch.stack([torch.randperm(M)[:k] for _ in range(N)]))
+    coeff, rows, W = dev(torch.randn(N, k)), dev(torch.randn(N, D)), dev(torch.randn(M, D))
+    seg = ops.build_latent_segments(idx, M)
+    gW0, gb0, dc0 = ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True)
+    gW = gW0.clone()
+    with pytest.raises(_lib.HipLibraryError) as err:
+        ops.segmented_weight_grad(seg, coeff, rows, W, want_bias=True, want_dcoeff=True, into=(gW, gb0.clone()))
+    assert err.value.status == _lib.SPHIP_EUNSUPPORTED and torch.equal(gW, gW0)
+    old = ops.TOKEN_BLOCK
+    ops.TOKEN_BLOCK = 128
+    try:
+        tW, tb, tdc = ops.weight_grad_in_token_blocks(idx, M, coeff, rows, W, want_bias=True, want_dcoeff=True)
+    finally:
+        ops.TOKEN_BLOCK = old
+    assert torch.equal(tW, gW0) and torch.equal(tb, gb0) and torch.equal(tdc, dc0)
+
+
 @pytest.mark.parametrize("R,D", [(1000, 96), (33, 4096), (4099, 288), (64, 32)])
 def test_slice_major_copy_ragged(device, R, D):
     """sphip_slice_major_f32 on row counts that are not whole 32-row tiles and slice counts that are
