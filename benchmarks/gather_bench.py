@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsify_amd import ops  # noqa: E402
 
-N, D, M, k = 16384, 4096, 131072, 192
+N, D, M, k = int(os.environ.get("TOKENS", "16384")), 4096, 131072, 192
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 W = torch.randn(M, D, device=dev, generator=g)

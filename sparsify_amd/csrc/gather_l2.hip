@@ -61,12 +61,18 @@ static L2Plan l2_plan(int64_t N, int64_t k, int64_t M) {
     return p;
 }
 
+#ifndef SPHIP_L2_MIN_USES
+// uses of a table row per launch below which the token-major form is taken. Headline widths, one box, L2 form
+// (+ 0.5 ms for the slice-major copy the decoder's step then writes) against the token-major form:
+// 6144 tokens 1.35 (+0.5) / 2.53 ms, 4096 tokens 1.01 (+0.5) / 1.70, 3072 tokens 0.83 (+0.5) / 1.28
+#define SPHIP_L2_MIN_USES 6
+#endif
 static bool l2_eligible(int64_t N, int64_t k, int64_t M, int64_t D) {
     if (D % 32 != 0 || N * k >= (1ll << 31) || M >= (1ll << 31) || N >= (1ll << 26)) return false;
     const int64_t B = cdiv(M, L2_BLOCK_ROWS);
     // worth it when the table is beyond the Infinity Cache, every (token, block) list still
     // holds a few entries, and every table row is used several times per launch
-    return B >= 2 && B <= L2_MAX_BLOCKS && M * D * 4 > (512ll << 20) && k >= 8 * B && N * k >= 8 * M;
+    return B >= 2 && B <= L2_MAX_BLOCKS && M * D * 4 > (512ll << 20) && k >= 8 * B && N * k >= SPHIP_L2_MIN_USES * M;
 }
 
 // One wave per token. SCATTER = false: start[b * N + n] = number of the token's slots whose
