@@ -224,7 +224,10 @@ int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, 
  * segments, coeff, rows and dcoeff; accumulate = 0 writes gW / gbias, != 0 adds the block's sums to
  * what an earlier call left there (fixed order: block after block). Built into the L2-sliced kernels
  * only: SPHIP_EUNSUPPORTED with accumulate != 0 for a shape that takes another form (nothing has
- * been added then; the caller sums the blocks' outputs itself). */
+ * been launched then; the caller sums the blocks' outputs itself). sphip_weight_grad_accumulates
+ * answers for a shape beforehand: ask for every block before the first call adds anything. */
+int sphip_weight_grad_accumulates(int64_t N, int64_t k, int64_t M, int64_t D, int rows_dtype,
+                                  int want_dcoeff);   /* 1: accumulate != 0 is available for this shape */
 int sphip_segmented_weight_grad_acc(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                     int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                                     float* gW, float* gbias, float* dcoeff, const float* row_shift,

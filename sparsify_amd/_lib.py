@@ -52,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_build_latent_segments": (_I, [_P, _L, _L, _L, _P, _P, _P, _Z, _P]),
     "sphip_weight_grad_workspace_bytes": (_Z, [_L, _L, _L]),
     "sphip_segmented_weight_grad": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P]),
+    "sphip_weight_grad_accumulates": (_I, [_L, _L, _L, _L, _I, _I]),
     "sphip_segmented_weight_grad_acc": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _I, _P]),
     "sphip_reduce_workspace_bytes": (_Z, [_L, _L]),
     "sphip_total_variance": (_I, [_P, _I, _L, _L, _P, _P, _Z, _P]),

@@ -83,6 +83,11 @@ class TrainConfig(_Serializable):
     """(not in the reference) "signsgd" on one rank without gradient accumulation: apply the step of
     `encoder.weight` inside its gradient kernel (same update; the (M, D) gradient is never
     materialised, so `encoder.weight.grad` stays None)."""
+    accumulate_in_kernel: bool = True
+    """(not in the reference) gradient accumulation (`grad_acc_steps * micro_acc_steps > 1`) on one rank: from the
+    second micro-step on the weight-gradient kernels add their sums to `encoder.weight.grad` / `W_dec.grad`
+    themselves instead of autograd adding a freshly written (M, D) tensor in a pass of its own (the same fp32
+    addition, the same bits; tensor hooks on these two parameters do not see those micro-steps)."""
     lazy_pre_acts: bool = False
     """(not in the reference) forward passes whose pre-activations nobody reads (no AuxK, no
     multi-top-k) do not store the (tokens, latents) matrix: top-k from candidate lists the GEMM

@@ -1239,6 +1239,23 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
                             int64_t k, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
                             void* stream, int accum = 0);
 
+// Whether the kernel form this shape takes can add into rows that are already there (the L2-sliced forms);
+// mirrors the dispatch of weight_grad_impl, which checks it before it launches anything.
+extern "C" int sphip_weight_grad_accumulates(int64_t N, int64_t k, int64_t M, int64_t D, int rows_dtype, int want_dcoeff) {
+    using namespace sphip;
+    if (N <= 0 || k <= 0 || M <= 0 || D <= 0 || !valid_dtype(rows_dtype) || N * k >= (1ll << 31) || D % 4 != 0) return 0;
+    const char* force = getenv("SPHIP_WGRAD");
+    const bool big = N * D * (int64_t)dtype_size(rows_dtype) >= (8ll << 20);
+    const int64_t C = rows_dtype == SPHIP_F32 ? Piece<float>::COLS : Piece<bf16_t>::COLS;
+    const bool sliced_ok = D % C == 0 && cdiv(cdiv(D, 8 * C), (int64_t)8) * cdiv(M, (int64_t)32) * 8 < (1ll << 31);
+    if (want_dcoeff)
+        return rows_dtype == SPHIP_F32 && l2dot_eligible(N, k, D) && D / 32 <= 65535 && sliced_ok &&
+               ((force && force[0] == 'l') || (!force && big && N * k >= 4 * M && N * 128 <= (3ll << 20)));
+    const bool want_wide = (force && force[0] == 'w') || (big && N * k >= SPHIP_WIDE_MEAN * M);
+    return !(force && (force[0] == 'f' || force[0] == 'w')) && !(wide_eligible(D) && !(force && force[0] == 'f') && want_wide) &&
+           sliced_ok;
+}
+
 extern "C" int sphip_segmented_weight_grad(const uint32_t* perm, const int32_t* seg_begin, const void* coeff,
                                            int coeff_dtype, const void* rows, int rows_dtype, const float* W,
                                            float* gW, float* gbias, float* dcoeff, const float* row_shift, int64_t N,
@@ -1283,6 +1300,9 @@ static int weight_grad_impl(const uint32_t* perm, const int32_t* seg_begin, cons
     SPHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need, SPHIP_EWORKSPACE,
                   "segmented_weight_grad: workspace %zu < %zu bytes", workspace_bytes, need);
     SPHIP_REQUIRE(((uintptr_t)workspace & 255) == 0, SPHIP_EINVAL, "segmented_weight_grad: workspace must be 256-byte aligned");
+    SPHIP_REQUIRE(!accum || sphip_weight_grad_accumulates(N, k, M, D, rows_dtype, dcoeff != nullptr), SPHIP_EUNSUPPORTED,
+                  "segmented_weight_grad_acc: this shape does not take an L2-sliced kernel (N=%lld k=%lld M=%lld D=%lld)",
+                  (long long)N, (long long)k, (long long)M, (long long)D);
     hipStream_t s = (hipStream_t)stream;
     const bool dot = dcoeff != nullptr;
     const int64_t E = N * k;

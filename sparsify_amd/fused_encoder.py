@@ -341,12 +341,9 @@ class FusedEncoder(torch.autograd.Function):
             # b_dec's encoder-side gradient -gb^T W (W before its update) rides in the fused kernel
             fold_bdec = need_bdec and not need_x
         elif need_w or need_b or need_bdec:
-            if indices.shape[0] > ops.TOKEN_BLOCK_LIMIT:
-                grad_weight, grad_bias, _ = ops.weight_grad_in_token_blocks(indices, M, gv, rows, want_bias=True,
-                                                                            row_shift=shift)
-            else:
-                seg = ops.cached_segments(indices, M)
-                grad_weight, grad_bias, _ = ops.segmented_weight_grad(seg, gv, rows, want_bias=True, row_shift=shift)
+            sink = ops.grad_sink(weight) if need_w else None        # gradient accumulation: see ops.register_grad_sinks
+            grad_weight, grad_bias, _, _ = ops.weight_grad_maybe_into(sink, indices, M, gv, rows, want_bias=True,
+                                                                      row_shift=shift)
             if bias is None:
                 gb_full, grad_bias = grad_bias, None
             else:

@@ -529,14 +529,20 @@ def token_blocks(N: int) -> list[tuple[int, int]]:
 
 
 def weight_grad_in_token_blocks(indices: Tensor, M: int, coeff: Tensor, rows: Tensor, W: Tensor | None = None,
-                                want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None):
+                                want_bias: bool = False, want_dcoeff: bool = False, row_shift: Tensor | None = None,
+                                into: tuple | None = None):
     """segmented_weight_grad over the whole batch, (gW, gbias, dcoeff), for batches whose row slices do not fit the
     L2-sliced kernels at once (N > TOKEN_BLOCK_LIMIT: the reference's default step is 32 x 2048 = 65536 tokens):
     blocks of <= TOKEN_BLOCK tokens, each with its own segments, the later ones adding their sums to the first one's
     (block after block: a fixed order). Where the shape takes a kernel form that cannot add, the whole batch goes
-    through one call as before."""
+    through one call as before. into = (gW, gbias or None): the first block adds to these as well."""
     N = indices.shape[0]
     blocks = token_blocks(N)
+    # asked for every block before the first one adds anything (blocks differ in size by a few tokens)
+    if not all(weight_grad_accumulates(hi - lo, coeff.shape[1], M, rows.shape[1], rows.dtype, want_dcoeff)
+               for lo, hi in (blocks if into is not None else blocks[1:])):
+        return segmented_weight_grad(cached_segments(indices, M), coeff, rows, W, want_bias=want_bias,
+                                     want_dcoeff=want_dcoeff, row_shift=row_shift, into=into)
     # decoder and encoder backward share the index tensor: the blocks' segments are sorted once per step, under
     # the same rules as cached_segments (made in backward, dropped by the next forward that sees the address)
     stamp = (indices._version, tuple(indices.shape), M, tuple(blocks))
@@ -549,21 +555,77 @@ def weight_grad_in_token_blocks(indices: Tensor, M: int, coeff: Tensor, rows: Te
     gW = gb = None
     dc = torch.empty(N, coeff.shape[1], dtype=torch.float32, device=rows.device) if want_dcoeff else None
     for b, (lo, hi) in enumerate(blocks):
-        seg = hit[1][b]
-        args = (seg, coeff[lo:hi], rows[lo:hi], W)
-        kw = dict(want_bias=want_bias, want_dcoeff=want_dcoeff, row_shift=row_shift,
-                  dcoeff_out=None if dc is None else dc[lo:hi])
-        if b == 0:
-            gW, gb, _ = segmented_weight_grad(*args, **kw)
-            continue
-        try:
-            segmented_weight_grad(*args, into=(gW, gb), **kw)
-        except _lib.HipLibraryError as err:
-            if b != 1 or getattr(err, "status", None) != _lib.SPHIP_EUNSUPPORTED:
-                raise
-            return segmented_weight_grad(build_latent_segments(indices, M), coeff, rows, W, want_bias=want_bias,
-                                         want_dcoeff=want_dcoeff, row_shift=row_shift)
+        gW, gb, _ = segmented_weight_grad(hit[1][b], coeff[lo:hi], rows[lo:hi], W, want_bias=want_bias,
+                                          want_dcoeff=want_dcoeff, row_shift=row_shift,
+                                          dcoeff_out=None if dc is None else dc[lo:hi],
+                                          into=into if b == 0 else (gW, gb))
     return gW, gb, dc
+
+
+# Gradient accumulation over micro-steps (trainer.py:444-447: loss / acc_steps, backward, one optimizer step per
+# grad_acc_steps): autograd adds a freshly written (M, D) gradient to `.grad` in a pass of its own, 6 GiB per matrix
+# and micro-step at the headline widths. For parameters registered here (the Trainer does, on one rank) the backward of
+# a later micro-step adds its sums to `.grad` inside the weight-gradient kernel instead (sphip_segmented_weight_grad_acc:
+# the same fp32 addition, so the same bits) and returns no gradient for them; tensor hooks on such a parameter do not
+# see these micro-steps' contributions.
+_grad_sinks: dict[int, object] = {}
+GRAD_SINK_HITS = 0
+
+
+def register_grad_sinks(params) -> None:
+    import weakref
+    for p in params:
+        _grad_sinks[p.data_ptr()] = weakref.ref(p)
+
+
+def clear_grad_sinks() -> None:
+    _grad_sinks.clear()
+
+
+def grad_sink(param: Tensor) -> Tensor | None:
+    """param.grad if `param` is registered and already holds a dense fp32 gradient to add to."""
+    ref = _grad_sinks.get(param.data_ptr())
+    p = ref() if ref is not None else None
+    if p is None or p is not param:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or g.device != p.device:
+        return None
+    return g
+
+
+def weight_grad_maybe_into(sink: Tensor | None, indices: Tensor, M: int, coeff: Tensor, rows: Tensor,
+                           W: Tensor | None = None, want_bias: bool = False, want_dcoeff: bool = False,
+                           row_shift: Tensor | None = None):
+    """(gW or None, gbias, dcoeff, added): the weight gradient of a backward pass, in token blocks where the batch
+    needs them; with a sink (grad_sink) the sums are added to it in the kernel and gW is None (added = True) unless
+    the shape takes a kernel form that cannot add (weight_grad_accumulates) -- then this is the ordinary call."""
+    global GRAD_SINK_HITS
+    N, k = coeff.shape
+    blocked = N > TOKEN_BLOCK_LIMIT
+    if sink is not None and all(weight_grad_accumulates(hi - lo, k, M, rows.shape[1], rows.dtype, want_dcoeff)
+                                for lo, hi in (token_blocks(N) if blocked else [(0, N)])):
+        # the bias sums are added to zeros: the same bits as written directly (the accumulate flag covers both outputs)
+        gb = torch.zeros(M, dtype=torch.float32, device=rows.device) if want_bias else None
+        if blocked:
+            _, _, dc = weight_grad_in_token_blocks(indices, M, coeff, rows, W, want_bias=want_bias,
+                                                   want_dcoeff=want_dcoeff, row_shift=row_shift, into=(sink, gb))
+        else:
+            _, _, dc = segmented_weight_grad(cached_segments(indices, M), coeff, rows, W, want_bias=want_bias,
+                                             want_dcoeff=want_dcoeff, row_shift=row_shift, into=(sink, gb))
+        GRAD_SINK_HITS += 1
+        return None, gb, dc, True
+    if blocked:
+        return (*weight_grad_in_token_blocks(indices, M, coeff, rows, W, want_bias=want_bias, want_dcoeff=want_dcoeff,
+                                             row_shift=row_shift), False)
+    return (*segmented_weight_grad(cached_segments(indices, M), coeff, rows, W, want_bias=want_bias,
+                                   want_dcoeff=want_dcoeff, row_shift=row_shift), False)
+
+
+def weight_grad_accumulates(N: int, k: int, M: int, D: int, rows_dtype, want_dcoeff: bool) -> bool:
+    """Whether segmented_weight_grad(..., into=...) is available for a call of this shape."""
+    code = F32 if rows_dtype == torch.float32 else BF16 if rows_dtype == torch.bfloat16 else -1
+    return bool(_lib.load().sphip_weight_grad_accumulates(N, k, M, D, code, int(want_dcoeff)))
 
 
 def segment_coeff_sums(seg: LatentSegments, coeff: Tensor) -> Tensor:

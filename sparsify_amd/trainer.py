@@ -156,6 +156,7 @@ class Trainer:
         # len(dataset) // batch_size, trainer.py:90)
         num_batches = max(len(source), 1) if hasattr(source, "__len__") else 1
         self._build_optimizers(num_batches)
+        self._register_grad_sinks()
 
         self.global_step = 0
         self.num_tokens_since_fired = {
@@ -247,6 +248,16 @@ class Trainer:
                 self._fused_projection = project
             case other:
                 raise ValueError(f"Unknown optimizer '{other}'")
+
+    def _register_grad_sinks(self):
+        """Gradient accumulation on one rank (or module owners, who exchange nothing): later micro-steps add into
+        the dense gradients inside the weight-gradient kernels (ops.register_grad_sinks)."""
+        cfg = self.cfg
+        one_rank = not (dist.is_initialized() and dist.get_world_size() > 1)
+        if (cfg.accumulate_in_kernel and cfg.grad_acc_steps * cfg.micro_acc_steps > 1 and not cfg.shard_latents
+                and (one_rank or cfg.distribute_modules) and self.device.type == "cuda"):
+            ops.register_grad_sinks([p for sae in self.saes.values() for p in (sae.encoder.weight, sae.W_dec)
+                                     if p is not None])
 
     # ------------------------------------------------------------------ k schedule (trainer.py:229-235)
     def get_current_k(self) -> int:

@@ -56,19 +56,16 @@ class SparseDecode(torch.autograd.Function):
         need_w, need_a = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gW = gA = gB = None
         if need_w or need_a:
-            if indices.shape[0] > ops.TOKEN_BLOCK_LIMIT:
-                # more tokens than the L2-sliced kernels take at once (the reference's default step: 65536)
-                gW, _, gA = ops.weight_grad_in_token_blocks(indices, weight.shape[0], psw.detach().contiguous(), g,
-                                                            weight.detach(), want_dcoeff=need_a)
-            else:
-                seg = ops.cached_segments(indices, weight.shape[0])
-                gW, _, gA = ops.segmented_weight_grad(seg, psw.detach().contiguous(), g, weight.detach(),
-                                                      want_dcoeff=need_a)
+            # in token blocks where the batch needs them (the reference's default step is 65536 tokens); on a later
+            # micro-step of a gradient-accumulating Trainer the sums are added to weight.grad inside the kernel
+            sink = ops.grad_sink(weight) if need_w else None
+            gW, _, gA, added = ops.weight_grad_maybe_into(sink, indices, weight.shape[0], psw.detach().contiguous(), g,
+                                                          weight.detach(), want_dcoeff=need_a)
             if gA is not None and gA.dtype != psw.dtype:
                 gA = gA.to(psw.dtype)
             if need_w:
                 from . import dead_decode
-                dead_decode.claim_pending_rows(weight, gW)     # AuxK rows of this backward pass (dead_decode.py)
+                dead_decode.claim_pending_rows(weight, sink if added else gW)     # AuxK rows of this backward pass (dead_decode.py)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gB = ops.colsum(g)
         return None, gW, gA, gB, None

@@ -315,6 +315,37 @@ def test_trainer_grad_accumulation_and_k_decay(device):
     assert not torch.equal(tr.saes["h0"].encoder.weight, w0)
 
 
+@pytest.mark.parametrize("optimizer,auxk", [("signsgd", 0.0), ("adam", 0.0), ("signsgd", 1 / 32)])
+def test_grad_accumulation_in_the_kernel_equals_autograd_accumulation(device, optimizer, auxk):
+    """TrainConfig.accumulate_in_kernel (trainer.py:444-447 + 510-520: loss / acc_steps per micro-step, one
+    optimizer step per grad_acc_steps): from the second micro-step on the weight-gradient kernels add into
+    encoder.weight.grad / W_dec.grad themselves. The same fp32 addition autograd would make, so two optimizer steps
+    of three micro-steps each must leave bit-identical parameters with the switch on and off -- AuxK rows (added to
+    the dense W_dec gradient by the main decode's backward) included."""
+    from sparsify_amd import SparseCoderConfig, TrainConfig, ops
+    from sparsify_amd.trainer import Trainer
+    D, M, k, N = 512, 2048, 16, 4096
+    batches = [b.cuda().to(torch.bfloat16) for b in make_batches(6, N, D)]
+    finals = []
+    for in_kernel in (True, False):
+        ops.clear_grad_sinks()
+        torch.manual_seed(0)
+        cfg = TrainConfig(sae=SparseCoderConfig(num_latents=M, k=k), optimizer=optimizer, lr=1e-3, grad_acc_steps=3,
+                          auxk_alpha=auxk, dead_feature_threshold=N, accumulate_in_kernel=in_kernel, save_dir="",
+                          save_every=10**9)
+        tr = Trainer(cfg, ListSource(batches, D), device="cuda")
+        hits0 = ops.GRAD_SINK_HITS
+        for b in batches:
+            tr.train_micro_batch({"h0": b})
+        torch.cuda.synchronize()
+        # two matrices x two later micro-steps x two optimizer steps
+        assert ops.GRAD_SINK_HITS - hits0 == (8 if in_kernel else 0)
+        finals.append({n: p.detach().clone() for n, p in tr.saes["h0"].named_parameters()})
+    ops.clear_grad_sinks()
+    for name in finals[0]:
+        assert torch.equal(finals[0][name], finals[1][name]), name
+
+
 @pytest.mark.parametrize("D", [64, 1024, 4096, 5120, 8192])
 def test_schedulefree_fused_step_equals_generic_path(device, monkeypatch, D):
     """ScheduleFreeWrapper(SignSGD): the one-kernel step (plain and decoder groups with projection
