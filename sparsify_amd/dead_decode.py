@@ -89,6 +89,45 @@ def _settle_pending_rows() -> None:
                 ops.scatter_add_rows_(w.grad, G, dead_list, num_dead)
 
 
+# The same for a whole dense gradient: the multi-top-k decode (sparse_coder.py:256-262) runs its backward before the
+# main decode's and would hand the engine a second (M, D) tensor to add (6 GiB of traffic at the headline shape).
+# It parks its gradient instead, under the same condition (a decode node over the same weight, noted in the forward,
+# is going to execute in this pass), and that node's weight-gradient kernels add their sums into it
+# (sphip_segmented_weight_grad_acc) and return it as theirs.
+_pending_dense: dict[int, list] = {}
+
+
+def park_dense(weight: Tensor, gW: Tensor) -> None:
+    _pending_dense.setdefault(weight.data_ptr(), []).append((weakref.ref(weight), gW))
+    torch.autograd.Variable._execution_engine.queue_callback(_settle_pending_dense)
+
+
+def claim_dense(weight: Tensor) -> Tensor | None:
+    """The dense gradient(s) parked for `weight` in this pass, as one tensor."""
+    total = None
+    for ref, G in _pending_dense.pop(weight.data_ptr(), []):
+        w = ref()
+        if w is not None and w.data_ptr() == weight.data_ptr() and w.shape == G.shape:
+            total = G if total is None else ops.add(total, G)
+        elif w is not None:                                     # another tensor at a recycled address
+            _pending_dense.setdefault(w.data_ptr(), []).append((ref, G))
+    return total
+
+
+def _settle_pending_dense() -> None:
+    for key in list(_pending_dense):
+        for ref, G in _pending_dense.pop(key, []):
+            w = ref()
+            if w is None:
+                continue
+            w.grad = G if w.grad is None else ops.add(w.grad, G)
+
+
+def later_decode_will_run(weight: Tensor, node) -> bool:
+    return (node is not None and weight.is_leaf and isinstance(weight, torch.nn.Parameter)
+            and torch._C._will_engine_execute_node(node))
+
+
 class DeadLatentDecode(torch.autograd.Function):
     """decode(auxk_acts, auxk_indices) for indices that all lie on dead latents; gradients for
     W_dec and b_dec only (the gradient w.r.t. the activations would flow into pre_acts, which

@@ -202,6 +202,36 @@ def _inplace_lr(weight: Tensor):
     return hit[1]
 
 
+# The block maxima the GEMM epilogue left for a stored pre_acts matrix (ops.encoder_preacts(..., want_tile_max=True)),
+# for a later top-k over the same matrix (multi-top-k, sparse_coder.py:257): address -> (weak reference to the
+# matrix, maxima). The entry dies with the matrix.
+_block_maxima: dict[int, tuple] = {}
+
+
+def note_block_maxima(pre: Tensor, tile_max: Tensor) -> None:
+    import weakref
+    key = pre.data_ptr()
+
+    def _drop(ref, key=key):
+        cur = _block_maxima.get(key)
+        if cur is not None and cur[0] is ref:
+            del _block_maxima[key]
+
+    _block_maxima[key] = (weakref.ref(pre, _drop), tile_max)
+
+
+def block_maxima_of(pre: Tensor) -> Tensor | None:
+    """The maxima noted for `pre` (or for a tensor `pre` is a same-shaped alias of), if it is still that matrix."""
+    hit = _block_maxima.get(pre.data_ptr())
+    if hit is None:
+        return None
+    owner = hit[0]()
+    if (owner is None or owner.data_ptr() != pre.data_ptr() or owner.numel() != pre.numel()
+            or owner.shape[-1] != pre.shape[-1] or owner._version != pre._version or owner._version != 0):
+        return None
+    return hit[1]
+
+
 def _autocast_bf16() -> bool:
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
@@ -309,8 +339,11 @@ class FusedEncoder(torch.autograd.Function):
         if lazy:
             ctx.mark_non_differentiable(indices)
             return values.reshape(*lead, k), indices.reshape(*lead, k), pre
+        pre = pre.reshape(*lead, pre.shape[-1])
         ctx.mark_non_differentiable(indices, pre)
-        return (values.reshape(*lead, k), indices.reshape(*lead, k), pre.reshape(*lead, pre.shape[-1]))
+        if tile_max is not None:
+            note_block_maxima(pre, tile_max)
+        return values.reshape(*lead, k), indices.reshape(*lead, k), pre
 
     @staticmethod
     def backward(ctx, grad_values, grad_indices, grad_preacts):

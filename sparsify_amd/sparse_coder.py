@@ -14,7 +14,7 @@ from torch import Tensor, nn
 
 from . import dead_decode, ops, parallel
 from .config import SparseCoderConfig
-from .fused_encoder import EncoderOutput, FusedEncoder, bf16_shadow, low_precision_input
+from .fused_encoder import EncoderOutput, FusedEncoder, bf16_shadow, block_maxima_of, low_precision_input
 from .utils import SparseDecode, decoder_impl
 
 
@@ -305,7 +305,8 @@ class SparseCoder(nn.Module):
 
         if self.cfg.multi_topk:
             pre2 = pre_acts.reshape(-1, pre_acts.shape[-1])
-            acts4, idx4 = ops.topk(pre2, 4 * self.cfg.k)                              # :257
+            # (the block maxima the GEMM left for this matrix spare the selection its first sweep)
+            acts4, idx4 = ops.topk(pre2, 4 * self.cfg.k, tile_max=block_maxima_of(pre_acts))   # :257
             top_acts4 = acts4.reshape(*x.shape[:-1], -1)
             top_indices4 = idx4.reshape(*x.shape[:-1], -1)
             if self.cfg.activation == "topk" and acts4.dtype == top_acts.dtype and self.W_dec is not None:

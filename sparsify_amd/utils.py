@@ -21,6 +21,11 @@ class SparseDecode(torch.autograd.Function):
         ops.forget_segments(indices)
         parallel.wait_for(weight)                  # an overlapped optimizer update (sign_sgd.py)
         w = weight.detach()
+        ctx.later_node = None
+        if summed is not None:
+            from . import dead_decode
+            # the decode noted last over this weight (SparseCoder.decode) runs its backward after this one
+            ctx.later_node = dead_decode._latest_decode_node(weight)
         ctx.empty = indices.shape[0] == 0
         if ctx.empty:                              # no rows: nothing to launch
             ops._req(indices, "indices", torch.int64, 2)
@@ -58,14 +63,24 @@ class SparseDecode(torch.autograd.Function):
         if need_w or need_a:
             # in token blocks where the batch needs them (the reference's default step is 65536 tokens); on a later
             # micro-step of a gradient-accumulating Trainer the sums are added to weight.grad inside the kernel
+            from . import dead_decode
             sink = ops.grad_sink(weight) if need_w else None
-            gW, _, gA, added = ops.weight_grad_maybe_into(sink, indices, weight.shape[0], psw.detach().contiguous(), g,
+            # a dense gradient an earlier node of this pass parked for the same weight (the multi-top-k decode)
+            parked = dead_decode.claim_dense(weight) if need_w else None
+            target = sink if sink is not None else parked
+            gW, _, gA, added = ops.weight_grad_maybe_into(target, indices, weight.shape[0], psw.detach().contiguous(), g,
                                                           weight.detach(), want_dcoeff=need_a)
             if gA is not None and gA.dtype != psw.dtype:
                 gA = gA.to(psw.dtype)
             if need_w:
-                from . import dead_decode
-                dead_decode.claim_pending_rows(weight, sink if added else gW)     # AuxK rows of this backward pass (dead_decode.py)
+                if added and target is parked:
+                    gW = parked
+                elif parked is not None:                        # (the kernel form could not add, or a sink took this one)
+                    gW = ops.add(gW, parked) if gW is not None else parked
+                dead_decode.claim_pending_rows(weight, sink if gW is None else gW)     # AuxK rows of this pass (dead_decode.py)
+                if gW is not None and dead_decode.later_decode_will_run(weight, ctx.later_node):
+                    dead_decode.park_dense(weight, gW)
+                    gW = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gB = ops.colsum(g)
         return None, gW, gA, gB, None

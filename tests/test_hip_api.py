@@ -423,3 +423,42 @@ def test_empty_batch_like_torch(device, autocast):
     out.sum().backward()
     for t in (x, W, b, Wd):
         assert t.grad is not None and t.grad.shape == t.shape and not t.grad.any()
+
+
+def test_multi_topk_dense_gradient_is_parked_for_the_main_decode(device, monkeypatch):
+    """Multi-top-k (sparse_coder.py:256-262): the 4k decode's backward runs first and parks its dense W_dec gradient;
+    the main decode's weight-gradient kernels add their sums into it (sphip_segmented_weight_grad_acc) instead of the
+    engine adding two (M, D) tensors. The same fp32 addition: W_dec.grad and every other gradient bit for bit what the
+    unparked pass gives; a backward of multi_topk_fvu alone (the main decode does not run) parks nothing."""
+    import importlib
+    from sparsify_amd import SparseCoder, SparseCoderConfig
+    dd = importlib.import_module("sparsify_amd.dead_decode")
+    N, D, M, k = 4096, 512, 2048, 16
+    torch.manual_seed(3)
+    sae = SparseCoder(D, SparseCoderConfig(num_latents=M, k=k, multi_topk=True)).cuda()
+    x = (torch.randn(N, D) + torch.randn(D)).to(torch.bfloat16).cuda()
+    parked = []
+    real_park = dd.park_dense
+    monkeypatch.setattr(dd, "park_dense", lambda w, g: (parked.append(1), real_park(w, g))[1])
+
+    def grads(loss_of, allow=True):
+        if not allow:
+            monkeypatch.setattr(dd, "later_decode_will_run", lambda w, n: False)
+        sae.zero_grad(set_to_none=True)
+        out = run_coder(sae, "bf16", x, None, None)
+        loss_of(out).backward()
+        monkeypatch.undo() if not allow else None
+        return {n: p.grad.clone() for n, p in sae.named_parameters() if p.grad is not None}
+
+    both = lambda o: o.fvu + o.multi_topk_fvu / 8
+    with_park = grads(both)
+    assert len(parked) == 1
+    monkeypatch.setattr(dd, "park_dense", lambda w, g: (parked.append(1), real_park(w, g))[1])
+    without = grads(both, allow=False)
+    assert len(parked) == 1
+    assert with_park.keys() == without.keys() and "W_dec" in with_park
+    for name in with_park:
+        assert torch.equal(with_park[name], without[name]), name
+    monkeypatch.setattr(dd, "park_dense", lambda w, g: (parked.append(1), real_park(w, g))[1])
+    alone = grads(lambda o: o.multi_topk_fvu)
+    assert len(parked) == 1 and "W_dec" in alone and not dd._pending_dense
