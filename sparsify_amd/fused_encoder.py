@@ -243,6 +243,11 @@ def low_precision_input(x2: Tensor, b_dec: Tensor | None) -> Tensor:
     return ops.center_cast(x2, None if b_dec is None else b_dec.detach().contiguous(), want_f32=False, want_bf16=True)[1]
 
 
+# the in-backward update of encoder.weight runs in the L2-sliced kernel: up to this mean segment length (entries per
+# latent and step)
+FUSE_MEAN_SEGMENT = int(os.environ.get("SPHIP_FUSE_MEAN", "64"))
+
+
 class FusedEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight, bias, k: int, activation: Literal["groupmax", "topk"], b_dec=None,
@@ -366,7 +371,7 @@ class FusedEncoder(torch.autograd.Function):
 
         lr_of = _inplace_lr(weight) if need_w else None
         fuse = (lr_of is not None and weight.is_contiguous() and rows.shape[1] % 8 == 0
-                and gv.numel() < 64 * M)                      # long segments take the wide kernel
+                and gv.numel() < FUSE_MEAN_SEGMENT * M)
         if fuse:
             seg = ops.cached_segments(indices, M)
             gb_full = ops.segment_coeff_sums(seg, gv)
