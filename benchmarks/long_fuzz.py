@@ -3,7 +3,8 @@ chunked long-segment path (wgrad.hip: latents with more than 128 entries, 128-en
 large share of the work: sphip_segmented_weight_grad with and without the dot part, fp32 / bf16 rows, fp32 / bf16
 coefficients (8- and 4-byte list entries), inactive slots, row shift -- against a float64 dense computation (2e-5
 of the largest element) -- and sphip_segmented_weight_grad_signsgd / _schedulefree against gradient + separate step
-(bit for bit), twice (identical bits). run(seconds, max_cases) is also what tests/test_hip_fuzz.py calls for a
+(bit for bit), twice (identical bits); the accumulate form against gW + gW (bit for bit) and the
+token-block driver against float64. run(seconds, max_cases) is also what tests/test_hip_fuzz.py calls for a
 bounded, seeded slice. Usage: python benchmarks/long_fuzz.py [seconds]"""
 import os
 import random
@@ -69,6 +70,28 @@ def run(budget: float = 60.0, max_cases: int | None = None) -> int:
             gW3, _, dc3 = ops.segmented_weight_grad(seg, coeff, rows, W, want_dcoeff=True)
             if not (torch.equal(gW2, gW3) and torch.equal(dc, dc3)):
                 raise AssertionError(f"MISMATCH (dot, second run differs) {what}")
+        # the accumulate form (sphip_segmented_weight_grad_acc): a second call over the same batch adds its sums to
+        # what is there -- bit for bit gW + gW, whatever the kernel form; the token-block driver over the batch cut at
+        # a random point against the float64 sums
+        dot = rdt == torch.float32 and shift is None and rng.random() < 0.5
+        if ops.weight_grad_accumulates(N, k, M, D, rdt, dot):
+            first = ops.segmented_weight_grad(seg, coeff, rows, W if dot else None, want_bias=True, want_dcoeff=dot, row_shift=shift)
+            acc_W, acc_b = first[0].clone(), first[1].clone()
+            ops.segmented_weight_grad(seg, coeff, rows, W if dot else None, want_bias=True, want_dcoeff=dot, row_shift=shift,
+                                      into=(acc_W, acc_b))
+            if not (torch.equal(acc_W, first[0] + first[0]) and torch.equal(acc_b, first[1] + first[1])):
+                raise AssertionError(f"MISMATCH (accumulate != gW + gW, dot={dot}) {what}")
+        old_block = ops.TOKEN_BLOCK
+        ops.TOKEN_BLOCK = max(64, N // rng.randint(2, 4) + rng.randint(0, 63))
+        try:
+            tW, tb, _ = ops.weight_grad_in_token_blocks(idx, M, coeff, rows, W if dot else None, want_bias=True,
+                                                        want_dcoeff=dot, row_shift=shift)
+        finally:
+            ops.TOKEN_BLOCK = old_block
+        err = float((tW.double() - want_gW).abs().max()) / scale
+        errb = float((tb.double() - want_gb).abs().max()) / max(1.0, float(want_gb.abs().max()))
+        if err > 2e-5 or errb > 2e-5:
+            raise AssertionError(f"MISMATCH (token blocks, dot={dot}) {what}: gW {err:.2e} gb {errb:.2e}")
         # (the fused step is what FusedEncoder.backward takes below a mean segment of 64 entries, fused_encoder.py;
         # beyond a mean of 256 the unfused gradient goes to the wave-per-latent kernel, another summation order)
         if N * k < 64 * M:
@@ -94,7 +117,7 @@ def run(budget: float = 60.0, max_cases: int | None = None) -> int:
         if time.time() - told > 30:
             told = time.time()
             print(f"... {n} cases", flush=True)
-    print(f"{n} random training-size cases in {time.time() - t0:.0f} s: long-segment path within 2e-5 of float64, fused = separate", flush=True)
+    print(f"{n} random training-size cases in {time.time() - t0:.0f} s: long-segment path and token blocks within 2e-5 of float64, fused = separate, accumulate = sum", flush=True)
     return n
 
 
