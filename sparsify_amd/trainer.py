@@ -388,9 +388,17 @@ class Trainer:
             self._metrics[f"multi_topk_fvu/{name}"] += out.multi_topk_fvu.detach() / denom
 
         acc_steps = cfg.grad_acc_steps * cfg.micro_acc_steps
-        loss = out.fvu + cfg.auxk_alpha * out.auxk_loss + out.multi_topk_fvu / 8    # trainer.py:444-446
+        # trainer.py:444-447: (fvu + alpha * auxk + multi_topk_fvu / 8) / acc_steps. Terms that are exact zeros and a
+        # division by one are left out: the same value and the same gradients without their dozen scalar kernels
+        loss = out.fvu
+        if cfg.auxk_alpha > 0:
+            loss = loss + cfg.auxk_alpha * out.auxk_loss
+        if cfg.sae.multi_topk:
+            loss = loss + out.multi_topk_fvu / 8
+        if acc_steps > 1:
+            loss = loss.div(acc_steps)
         self._arm_grad_reduce()
-        loss.div(acc_steps).backward()
+        loss.backward()
         return out, n_tokens
 
     # ------------------------------------------------------------------ the step tail (trainer.py:510-538)
