@@ -15,6 +15,9 @@ from . import _lib
 from ._lib import BF16, F32, check
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _dt(t: Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -24,6 +27,10 @@ def _dt(t: Tensor) -> int:
 
 
 def _stream(t: Tensor) -> int:
+    """The current stream of t's device as a hipStream_t. (A dozen calls per step: the raw handle costs a tenth of
+    building a torch.cuda.Stream object for it, which shows on launch-bound shapes.)"""
+    if _raw_stream is not None and t.device.index is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -84,7 +91,9 @@ _workspaces: dict[tuple, Tensor] = {}
 
 def _workspace(device: torch.device, nbytes: int, tag: str) -> Tensor:
     """Grow-only per-(device, stream, tag) scratch buffer (uint8, 256-B aligned by the allocator)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    stream = (_raw_stream(device.index) if _raw_stream is not None and device.index is not None
+              else torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         # whole 2 MiB units: with an odd size the caching allocator placed the 290 MB weight-gradient
