@@ -179,20 +179,26 @@ def test_config1_pythia160m_shape_all_layers(device):
         assert abs(curves[follow][s] - want) <= tol * want, (s, curves[follow][s], want)
 
 
-def test_step_on_more_tokens_than_one_block_vs_oracle(device):
+@pytest.mark.parametrize("variant", ["plain", "auxk", "multitopk"])
+def test_step_on_more_tokens_than_one_block_vs_oracle(device, variant):
     """N = 26000 tokens in one step: more than the L2-sliced weight-gradient kernels take at once (24576), so both
     backward passes go through ops.weight_grad_in_token_blocks (two blocks, the second adding to the first). The
     reference's index_add_ / atomics take any number of rows (fused_encoder.py:67-84, xformers.py:110-136; its
-    default step is 65536 tokens); forward, losses and every gradient against the oracle on the same selection."""
+    default step is 65536 tokens); forward, losses and every gradient against the oracle on the same selections.
+    auxk: a tenth of the latents dead -- the dense AuxK path parks its gradient rows for the main decode's backward,
+    which adds them to the blocks' sum. multitopk: the 4k decode's backward (all 4k slots, in blocks too) parks its
+    dense gradient and the main decode's blocks add into it."""
     from oracle import sae_oracle as O
     from sparsify_amd import SparseCoder, SparseCoderConfig, ops
     from test_hip_api import run_coder, same_topk_sets
     N, D, M, k = 26000, 512, 2048, 16
+    alpha = 1 / 32 if variant == "auxk" else 0.0
     assert N > ops.TOKEN_BLOCK_LIMIT and len(ops.token_blocks(N)) == 2
     torch.manual_seed(0)
-    sae = SparseCoder(D, SparseCoderConfig(num_latents=M, k=k)).cuda()
+    sae = SparseCoder(D, SparseCoderConfig(num_latents=M, k=k, multi_topk=(variant == "multitopk"))).cuda()
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(N, D, generator=g) + torch.randn(D, generator=g)).to(torch.bfloat16).cuda()
+    dead = (torch.rand(M, generator=g) < 0.1) if variant == "auxk" else None
     with torch.no_grad():
         sae.b_dec.copy_(x.float().mean(0))
     P = {"W_enc": sae.encoder.weight.detach().cpu().clone(), "b_enc": sae.encoder.bias.detach().cpu().clone(),
@@ -200,19 +206,33 @@ def test_step_on_more_tokens_than_one_block_vs_oracle(device):
     ops.timer.enabled = True
     ops.timer.reset()
     try:
-        out = run_coder(sae, "bf16", x, None, None)
-        out.fvu.backward()
+        out = run_coder(sae, "bf16", x, None, None if dead is None else dead.cuda())
+        (out.fvu + alpha * out.auxk_loss + out.multi_topk_fvu / 8).backward()
         torch.cuda.synchronize()
         calls = ops.timer.summary()
     finally:
         ops.timer.enabled = False
-    assert calls["sphip_segmented_weight_grad"]["calls"] == 4           # two blocks x (W_dec, encoder.weight)
-    assert calls["sphip_build_latent_segments"]["calls"] == 2           # sorted once per block, shared by the two
-    forced = {"top": (out.latent_acts.detach().cpu(), out.latent_indices.cpu())}
-    ref, G = O.forward_backward(P, x.cpu(), None, O.OracleConfig(k=k), bf16=True, forced=forced)
-    same_topk_sets(out.latent_indices.cpu(), O.select_latents(ref["pre_acts"], k, "topk")[1], ref["pre_acts"], k, margin=2**-7)
+    # two blocks x (W_dec, encoder.weight), sorted once per block; the 4k decode's gradient (812 entries per latent
+    # here) takes the wave-per-latent kernel, which cannot add: the whole batch in one call, one more sort
+    blocks_4k = all(ops.weight_grad_accumulates(hi - lo, 4 * k, M, D, torch.float32, False) for lo, hi in ops.token_blocks(N))
+    extra = 0 if variant != "multitopk" else (2 if blocks_4k else 1)
+    assert calls["sphip_segmented_weight_grad"]["calls"] == 4 + extra
+    assert calls["sphip_build_latent_segments"]["calls"] == 2 + extra
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        enc = sae.encode(x)
+    forced = {"top": (enc.top_acts.cpu(), enc.top_indices.cpu())}
+    if variant == "multitopk":
+        forced["multi"] = (out.latent_acts.detach().cpu(), out.latent_indices.cpu())
+    if dead is not None:
+        assert "sphip_gemm_bf16_f32acc" in calls                            # the dense AuxK path ran
+        a_acts, a_idx = ops.topk(enc.pre_acts, D // 2 if int(dead.sum()) >= D // 2 else int(dead.sum()), keep_mask=dead.cuda())
+        forced["aux"] = (a_acts.cpu(), a_idx.cpu())
+    cfg = O.OracleConfig(k=k, multi_topk=(variant == "multitopk"))
+    ref, G = O.forward_backward(P, x.cpu(), None, cfg, dead_mask=dead, auxk_alpha=alpha, bf16=True, forced=forced)
+    same_topk_sets(enc.top_indices.cpu(), O.select_latents(ref["pre_acts"], k, "topk")[1], ref["pre_acts"], k, margin=2**-7)
     torch.testing.assert_close(out.sae_out.detach().cpu(), ref["sae_out"], rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(float(out.fvu.detach()), float(ref["fvu"]), rtol=2e-4, atol=1e-6)
+    for key, val in (("fvu", out.fvu), ("auxk_loss", out.auxk_loss), ("multi_topk_fvu", out.multi_topk_fvu)):
+        torch.testing.assert_close(float(val.detach()), float(ref[key]), rtol=2e-4, atol=1e-6)
     grads = {"W_enc": sae.encoder.weight.grad, "b_enc": sae.encoder.bias.grad, "W_dec": sae.W_dec.grad, "b_dec": sae.b_dec.grad}
     for pname, gr in grads.items():
         rel = (gr.cpu() - G[pname]).norm() / G[pname].norm().clamp_min(1e-12)
