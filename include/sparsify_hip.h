@@ -288,6 +288,12 @@ int sphip_remove_parallel_grad(float* G, const float* W, int64_t M, int64_t D, v
  * in the same pass (bf16_shadow may be NULL). */
 int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow,
                        void* stream);
+/* The same step (sign_sgd.py:23) for an (M, D) matrix whose slice-major copy [D/32][M][32] (see
+ * sphip_slice_major_f32) is rewritten in the same pass while the rows are in registers: a decoder
+ * that is neither projected nor normalised (a transcoder's, trainer.py:406-408 / 513-518 do not
+ * apply) read by the L2-resident decode. slice_major may be NULL. Bit for bit sphip_signsgd_step. */
+int sphip_signsgd_step_rows(float* W, const float* G, int64_t M, int64_t D, float lr,
+                            float* slice_major, void* stream);
 
 /* torch.optim.Adam's step (the "adam" optimizer of trainer.py:92-122 when bitsandbytes is absent:
  * betas, eps, no weight decay, no amsgrad) for one parameter: exp_avg / exp_avg_sq / p updated in

@@ -64,6 +64,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_unit_norm_rows": (_I, [_P, _L, _L, _P]),
     "sphip_remove_parallel_grad": (_I, [_P, _P, _L, _L, _P]),
     "sphip_signsgd_step": (_I, [_P, _P, _L, _F, _P, _P]),
+    "sphip_signsgd_step_rows": (_I, [_P, _P, _L, _L, _F, _P, _P]),
     "sphip_decoder_project_signsgd": (_I, [_P, _P, _L, _L, _F, _I, _P, _P]),
     "sphip_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
     "sphip_decoder_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P, _P]),

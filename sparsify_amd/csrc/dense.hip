@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void decoder_row_kernel(float* __restrict__ W,
 // OP 0: W /= ||W|| + eps.   OP 1: W -= lr * sign(G - <G,W> W).   OP 2: OP 1 then OP 0 on the
 // updated row (optimizer step + the re-normalisation that opens the next train step,
 // trainer.py:408). The reductions add in the same order as the two-sweep kernels above, so
-// results are bitwise identical to them.
+// results are bitwise identical to them. OP 3: W -= lr * sign(G), the plain SignSGD step (a
+// transcoder's decoder, which is neither projected nor normalised): signsgd_kernel's arithmetic,
+// here for the sake of SM.
 // SM (needs D % 32 == 0): the finished row also goes to the slice-major copy [D/32][M][32] the
 // L2-resident decode gathers from (sphip_slice_major_f32), while it is in registers: the separate
 // copy pass (2 GiB read + 2 GiB written at the headline shape) becomes 2 GiB of extra stores.
@@ -172,7 +174,15 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
         b[i] = c < D ? ld(w + c, (SPHIP_DEC_NT & 1) != 0) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (OP != 0) a[i] = c < D ? ld(g + c, (SPHIP_DEC_NT & 2) != 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (OP != 0) {
+    if (OP == 3) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            b[i].x -= lr * (float)((a[i].x > 0.f) - (a[i].x < 0.f));
+            b[i].y -= lr * (float)((a[i].y > 0.f) - (a[i].y < 0.f));
+            b[i].z -= lr * (float)((a[i].z > 0.f) - (a[i].z < 0.f));
+            b[i].w -= lr * (float)((a[i].w > 0.f) - (a[i].w < 0.f));
+        }
+    } else if (OP != 0) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void decoder_row_resident_kernel(float* __rest
             b[i].w -= lr * (float)((p.w > 0.f) - (p.w < 0.f));
         }
     }
-    if (OP != 1) {
+    if (OP == 0 || OP == 2) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -711,6 +721,25 @@ extern "C" int sphip_decoder_project_signsgd(float* W, const float* G, int64_t M
     }
     int st = decoder_row_op(W, const_cast<float*>(G), M, D, lr, 1, stream, "decoder_project_signsgd");
     if (st == SPHIP_OK && renorm) st = sphip_unit_norm_rows(W, M, D, stream);
+    if (st == SPHIP_OK && slice_major != nullptr) st = sphip_slice_major_f32(W, slice_major, M, D, stream);
+    return st;
+}
+
+extern "C" int sphip_signsgd_step(float* p, const float* g, int64_t n, float lr, void* bf16_shadow, void* stream);
+
+extern "C" int sphip_signsgd_step_rows(float* W, const float* G, int64_t M, int64_t D, float lr, float* slice_major,
+                                       void* stream) {
+    using namespace sphip;
+    SPHIP_REQUIRE(W && G, SPHIP_EINVAL, "signsgd_step_rows: null pointer");
+    SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && D < (1ll << 31), SPHIP_EINVAL, "signsgd_step_rows: bad shape");
+    SPHIP_REQUIRE(slice_major == nullptr || (D % 32 == 0 && ((uintptr_t)slice_major & 15) == 0), SPHIP_EINVAL,
+                  "signsgd_step_rows: the slice-major copy needs D %% 32 == 0 and a 16-byte aligned buffer");
+    if (launch_row_resident<3>(W, G, M, D, lr, SPHIP_F32_EPS, (hipStream_t)stream, slice_major)) {
+        SPHIP_CHECK_LAUNCH("signsgd_step_rows");
+        return SPHIP_OK;
+    }
+    SPHIP_REQUIRE((M * D) % 8 == 0, SPHIP_EUNSUPPORTED, "signsgd_step_rows: M * D must be a multiple of 8");
+    int st = sphip_signsgd_step(W, G, M * D, lr, nullptr, stream);
     if (st == SPHIP_OK && slice_major != nullptr) st = sphip_slice_major_f32(W, slice_major, M, D, stream);
     return st;
 }

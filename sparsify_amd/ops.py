@@ -804,6 +804,24 @@ def signsgd_step_(p: Tensor, g: Tensor, lr: float, bf16_shadow: Tensor | None = 
     return p
 
 
+def signsgd_step_rows_(W: Tensor, G: Tensor, lr: float, slice_major: Tensor | None = None) -> Tensor:
+    """signsgd_step_ for an (M, D) matrix, rewriting its slice-major copy (the buffer the L2-resident decode
+    gathers from) in the same pass: a decoder matrix that is neither projected nor normalised (transcoders)."""
+    _req(W, "W", torch.float32, 2)
+    _req(G, "grad", torch.float32, 2)
+    if G.shape != W.shape:
+        raise ValueError("signsgd_step_rows: grad shape mismatch")
+    if slice_major is not None:
+        _req(slice_major, "slice_major", torch.float32)
+        if slice_major.numel() != W.numel() or W.shape[1] % 32:
+            raise ValueError("signsgd_step_rows: slice-major buffer does not match W")
+    _ev = timer.start("sphip_signsgd_step_rows", W)
+    check(_lib.load().sphip_signsgd_step_rows(W.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1], float(lr),
+                                             _ptr(slice_major), _stream(W)), "sphip_signsgd_step_rows")
+    timer.stop(_ev, W)
+    return W
+
+
 def adam_step_(p: Tensor, g: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float,
                eps: float, step: int, bf16_shadow: Tensor | None = None) -> Tensor:
     """torch.optim.Adam's update of one parameter (no weight decay, no amsgrad), one pass; step counts from 1."""

@@ -126,6 +126,15 @@ class SignSGD(Optimizer):
                         self.renormalised.add(id(p))
                     continue
                 shadow = peek_bf16_shadow(p)
+                sm = (ops.peek_slice_major(p) if shadow is None and p.ndim == 2 and p.is_contiguous()
+                      and os.environ.get("SPHIP_SM_FOLD", "1") != "0" else None)
+                if sm is not None:
+                    # a decoder matrix that is neither projected nor normalised (a transcoder's) and that the
+                    # L2-resident decode reads through its slice-major copy: rewritten in the same pass
+                    ops.signsgd_step_rows_(p.data, g, lr, sm)
+                    torch.autograd.graph.increment_version(p)
+                    ops.register_slice_major(p, sm)
+                    continue
                 ops.signsgd_step_(p.data, g, lr, shadow)
                 torch.autograd.graph.increment_version(p)
                 if shadow is not None:

@@ -961,6 +961,24 @@ def test_decoder_step_writes_the_slice_major_copy(device, D, renorm):
     assert torch.equal(buf, got.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
 
 
+@pytest.mark.parametrize("M,D", [(1000, 256), (777, 4096), (64, 8192), (333, 96), (50, 12288)])
+def test_plain_signsgd_row_step_writes_the_slice_major_copy(device, M, D):
+    """sphip_signsgd_step_rows (a transcoder's decoder: SignSGD.step, sign_sgd.py:15-23, no projection, no
+    normalisation): the parameter bit for bit sphip_signsgd_step's, zero gradients leaving their elements alone, and
+    the buffer the slice-major form of the updated matrix -- rows wider than the row-resident kernel takes included."""
+    from sparsify_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + D)
+    W0 = torch.randn(M, D, device="cuda", generator=g)
+    G = torch.randn(M, D, device="cuda", generator=g)
+    G[::7] = 0.0
+    plain = ops.signsgd_step_(W0.clone(), G, 3e-3)
+    buf = torch.full((D // 32, M, 32), float("nan"), device="cuda")
+    got = ops.signsgd_step_rows_(W0.clone(), G, 3e-3, buf)
+    assert torch.equal(got, plain) and torch.equal(got[::7], W0[::7])
+    assert torch.equal(buf, got.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
+    assert torch.equal(ops.signsgd_step_rows_(W0.clone(), G, 3e-3, None), plain)
+
+
 @pytest.mark.parametrize("D", [64, 1024, 2560, 4096])
 @pytest.mark.parametrize("renorm", [False, True])
 def test_schedulefree_decoder_step_writes_the_slice_major_copy(device, D, renorm):
