@@ -332,6 +332,11 @@ int sphip_schedulefree_signsgd_step(float* p, float* z, const float* g, int64_t 
 int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M,
                                             int64_t D, float lr, float beta, float c, int renorm,
                                             float* slice_major, void* stream);
+/* sphip_schedulefree_signsgd_step for an (M, D) matrix with its slice-major copy rewritten in the same
+ * pass and no projection (a transcoder's decoder; D % 4 == 0, D <= 8192). Bit for bit the flat step. */
+int sphip_schedulefree_signsgd_step_rows(float* W, float* Z, const float* G, int64_t M, int64_t D,
+                                         float lr, float beta, float c, float* slice_major,
+                                         void* stream);
 
 /* The encoder weight gradient fused with its SignSGD step (fused_encoder.py:67-77 +
  * sign_sgd.py:23): the segmented reduction of sphip_segmented_weight_grad (without dcoeff), but

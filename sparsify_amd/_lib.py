@@ -68,6 +68,7 @@ SIGNATURES: dict[str, tuple] = {
     "sphip_decoder_project_signsgd": (_I, [_P, _P, _L, _L, _F, _I, _P, _P]),
     "sphip_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _P, _P]),
     "sphip_decoder_schedulefree_signsgd_step": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _I, _P, _P]),
+    "sphip_schedulefree_signsgd_step_rows": (_I, [_P, _P, _P, _L, _L, _F, _F, _F, _P, _P]),
     "sphip_dead_compact": (_I, [_P, _L, _P, _P, _L, _P]),
     "sphip_dead_scatter_acts": (_I, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _P, _P]),
     "sphip_split_bf16_transposed": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),

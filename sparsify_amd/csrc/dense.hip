@@ -483,7 +483,9 @@ __global__ __launch_bounds__(256) void sf_decoder_kernel(float* __restrict__ W, 
         acc = fmaf(a[i].x, y[i].x, acc); acc = fmaf(a[i].y, y[i].y, acc);
         acc = fmaf(a[i].z, y[i].z, acc); acc = fmaf(a[i].w, y[i].w, acc);
     }
-    const float par = block_sum(acc, red);
+    // renorm: bit 0 = normalise the new row, bit 1 = no projection (the plain step of a matrix that is neither
+    // projected nor normalised, sphip_schedulefree_signsgd_step_rows: a - 0 * y is a, bit for bit)
+    const float par = (renorm & 2) ? 0.f : block_sum(acc, red);
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256) void sf_decoder_kernel(float* __restrict__ W, 
             ss = fmaf(y[i].z, y[i].z, ss); ss = fmaf(y[i].w, y[i].w, ss);
         }
     }
-    if (renorm) {
+    if (renorm & 1) {
         const float denom = sqrtf(block_sum(ss, red)) + eps;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -916,8 +918,8 @@ extern "C" int sphip_schedulefree_signsgd_step(float* p, float* z, const float* 
     return SPHIP_OK;
 }
 
-extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr,
-                                                       float beta, float c, int renorm, float* slice_major, void* stream) {
+static int sf_row_step(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr, float beta, float c, int renorm,
+                       float* slice_major, void* stream) {
     using namespace sphip;
     SPHIP_REQUIRE(W && Z && G, SPHIP_EINVAL, "decoder_schedulefree_signsgd_step: null pointer");
     SPHIP_REQUIRE(M > 0 && D > 0 && M < (1ll << 31) && beta > 0.f && beta <= 1.f, SPHIP_EINVAL,
@@ -944,6 +946,16 @@ extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const
     else hipLaunchKernelGGL((sf_decoder_kernel<8>), grid, block, 0, s, W, Z, G, (int)D, lr, wu, c, wy, renorm, SPHIP_F32_EPS);
     SPHIP_CHECK_LAUNCH("decoder_schedulefree_signsgd_step");
     return SPHIP_OK;
+}
+
+extern "C" int sphip_decoder_schedulefree_signsgd_step(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr,
+                                                       float beta, float c, int renorm, float* slice_major, void* stream) {
+    return sf_row_step(W, Z, G, M, D, lr, beta, c, renorm ? 1 : 0, slice_major, stream);
+}
+
+extern "C" int sphip_schedulefree_signsgd_step_rows(float* W, float* Z, const float* G, int64_t M, int64_t D, float lr,
+                                                    float beta, float c, float* slice_major, void* stream) {
+    return sf_row_step(W, Z, G, M, D, lr, beta, c, 2, slice_major, stream);
 }
 
 extern "C" int sphip_schedulefree_apply_signs(float* p, float* z, const int8_t* signs, int64_t n, float lr, float beta,

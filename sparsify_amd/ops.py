@@ -877,6 +877,27 @@ def decoder_schedulefree_signsgd_step_(W: Tensor, Z: Tensor, G: Tensor, lr: floa
     return W
 
 
+def schedulefree_signsgd_step_rows_(W: Tensor, Z: Tensor, G: Tensor, lr: float, beta: float, c: float,
+                                    slice_major: Tensor | None = None) -> Tensor:
+    """schedulefree_signsgd_step_ for an (M, D) matrix (no projection, no normalisation: a transcoder's decoder)
+    that rewrites its slice-major copy in the same pass. D % 4 == 0, D <= 8192."""
+    _req(W, "W", torch.float32, 2)
+    _req(Z, "z", torch.float32, 2)
+    _req(G, "grad", torch.float32, 2)
+    if Z.shape != W.shape or G.shape != W.shape:
+        raise ValueError("schedulefree_signsgd_step_rows: shape mismatch")
+    if slice_major is not None:
+        _req(slice_major, "slice_major", torch.float32)
+        if slice_major.numel() != W.numel() or W.shape[1] % 32:
+            raise ValueError("schedulefree_signsgd_step_rows: slice_major must hold M * D floats, D % 32 == 0")
+    _ev = timer.start("sphip_schedulefree_signsgd_step_rows", W)
+    check(_lib.load().sphip_schedulefree_signsgd_step_rows(W.data_ptr(), Z.data_ptr(), G.data_ptr(), W.shape[0], W.shape[1],
+                                                          float(lr), float(beta), float(c), _ptr(slice_major), _stream(W)),
+          "sphip_schedulefree_signsgd_step_rows")
+    timer.stop(_ev, W)
+    return W
+
+
 # ---- sign exchange (data-parallel SignSGD, parallel.SignExchange)
 def sign_i8(g: Tensor, out: Tensor | None = None) -> Tensor:
     """int8 sign(g) (-1 / 0 / +1)."""

@@ -174,7 +174,13 @@ class ScheduleFreeWrapper:
                         self.base.renormalised.add(id(p))
                 else:
                     shadow = peek_bf16_shadow(p)
-                    ops.schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, shadow)
+                    if (shadow is None and p.ndim == 2 and p.is_contiguous() and p.shape[1] % 32 == 0
+                            and p.shape[1] <= 8192):
+                        sm = ops.peek_slice_major(p)      # a transcoder's decoder, read by the L2-resident decode
+                    if sm is not None:
+                        ops.schedulefree_signsgd_step_rows_(p.data, st["z"], g, group["lr"], self.momentum, c, sm)
+                    else:
+                        ops.schedulefree_signsgd_step_(p.data, st["z"], g, group["lr"], self.momentum, c, shadow)
                     if shadow is not None:
                         register_bf16_shadow(p, shadow)
                 torch.autograd.graph.increment_version(p)

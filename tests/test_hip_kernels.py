@@ -979,6 +979,25 @@ def test_plain_signsgd_row_step_writes_the_slice_major_copy(device, M, D):
     assert torch.equal(ops.signsgd_step_rows_(W0.clone(), G, 3e-3, None), plain)
 
 
+@pytest.mark.parametrize("M,D", [(1000, 256), (777, 4096), (64, 8192), (333, 96)])
+def test_plain_schedulefree_row_step_writes_the_slice_major_copy(device, M, D):
+    """sphip_schedulefree_signsgd_step_rows: y and z bit for bit the flat schedule-free step's, the buffer the
+    slice-major form of the new y."""
+    from sparsify_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + D + 1)
+    W0 = torch.randn(M, D, device="cuda", generator=g)
+    Z0 = W0 + 0.01 * torch.randn(M, D, device="cuda", generator=g)
+    G = torch.randn(M, D, device="cuda", generator=g)
+    G[::5] = 0.0
+    Wr, Zr = W0.clone(), Z0.clone()
+    ops.schedulefree_signsgd_step_(Wr, Zr, G, 3e-3, 0.95, 0.25, None)
+    buf = torch.full((D // 32, M, 32), float("nan"), device="cuda")
+    Wf, Zf = W0.clone(), Z0.clone()
+    ops.schedulefree_signsgd_step_rows_(Wf, Zf, G, 3e-3, 0.95, 0.25, buf)
+    assert torch.equal(Wf, Wr) and torch.equal(Zf, Zr)
+    assert torch.equal(buf, Wf.view(M, D // 32, 32).permute(1, 0, 2).contiguous())
+
+
 @pytest.mark.parametrize("D", [64, 1024, 2560, 4096])
 @pytest.mark.parametrize("renorm", [False, True])
 def test_schedulefree_decoder_step_writes_the_slice_major_copy(device, D, renorm):
