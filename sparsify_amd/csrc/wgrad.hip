@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FUSE ? SPHI
     if (DOT) {
 #pragma unroll
         for (int c = 0; c < C; ++c) wdot[c] = 0.f;
-        if (live) {
+        if (live && end > beg) {                        // (a latent nobody selected has no dots to take)
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
