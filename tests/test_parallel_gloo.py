@@ -147,8 +147,9 @@ def _sharded_topk(rank, world):
     return torch.equal(mv, ref.values) and torch.equal(midx.sort(-1).values, ref.indices.sort(-1).values)
 
 
-def test_latent_sharded_topk_merge_equals_global_topk():
-    assert all(launch(_sharded_topk))
+@pytest.mark.parametrize("world", [2, 4])
+def test_latent_sharded_topk_merge_equals_global_topk(world):
+    assert all(launch(_sharded_topk, world=world))
 
 
 def _sign_exchange(rank, world):
@@ -167,7 +168,9 @@ def _sign_exchange(rank, world):
     p = W.clone()
     P.SignExchange.step(grads[rank], lambda s, lo, hi: torch.sign(s).to(torch.int8),
                         lambda signs, lo, hi: p[lo:hi].sub_(lr * signs.float()))
-    ok_plain = torch.equal(p, W - lr * torch.sign(mean))
+    # (beyond two ranks the reduction's summation order may differ from sum(): a ~0 mean can flip its sign)
+    ok_plain = torch.equal(p, W - lr * torch.sign(mean)) if world == 2 else \
+        float((p != W - lr * torch.sign(mean)).float().mean()) < 1e-5
     # the same update exchanged in row blocks (what the overlapped optimizer step does)
     p2 = W.clone()
     order = []
@@ -191,8 +194,9 @@ def _sign_exchange(rank, world):
     return ok_plain, frac_bad, seen[0] == (rank * M // world, (rank + 1) * M // world)
 
 
-def test_sign_exchange_equals_step_on_mean_gradient():
-    for ok_plain, frac_bad, block_ok in launch(_sign_exchange):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sign_exchange_equals_step_on_mean_gradient(world):
+    for ok_plain, frac_bad, block_ok in launch(_sign_exchange, world=world):
         assert ok_plain and block_ok
         assert frac_bad < 1e-5
 
